@@ -1,0 +1,1569 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see pto_math.h).
+//
+// CPU restatement of the reference's per-pixel integration loop
+// (CouncilmanJeremyJamm/path_tracer @ /root/reference, Rust).  Every function
+// cites the reference file:line it follows.  Control flow, stack discipline,
+// RNG draw order and floating-point operation order mirror the source text.
+//
+// Documented deviations:
+//   B-1  Sobol index = true sample index (reference passes c.w as u32 = 0/1).
+//   B-8  LightSampler::sample index clamped to len-1 (reference would panic).
+//   B-13 volume stack = insertion-ordered small vector keyed by material index
+//        (reference: pointer-keyed hash set with address-dependent order).
+//   RNG  thread-local entropy-seeded WyRand -> counter-based WyRand stream per
+//        (seed, pixel, sample); libm sin_cos/tan/exp/ln -> det_* of pto_math.h.
+#include "pt_oracle.h"
+#include "pto_math.h"
+
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <thread>
+#include <vector>
+
+using namespace pto;
+
+namespace {
+
+const float EPSILON = 5e-04f;          // utility.rs:4
+const float INF = INFINITY;            // utility.rs:5
+const float PI_F = 3.14159265358979323846f;
+const float TAU_F = 6.28318530717958647692f;
+const float FRAC_1_PI = 0.318309886183790671537767526745028724f;
+
+struct Counters
+{
+    uint64_t c[PTO_N_COUNTERS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int mode = -1; // which counter class the current traversal feeds (0 world closest, 1 any, 2 lights closest)
+    void node() { c[3]++; if (mode == 0) c[6]++; }
+    void tri() { c[4]++; if (mode == 0) c[7]++; }
+};
+
+// ------------------------------------------------------------------ ray.rs
+struct Ray
+{
+    V3 o, d, inv;
+    static Ray make(V3 o, V3 d) { return Ray{o, d, recip(d)}; }                 // ray.rs:10-18
+    V3 at(float t) const { return vfma(d, splat(t), o); }                        // ray.rs:20 (mul_add)
+    Ray transform(const Affine& inv_m) const                                     // ray.rs:22-28
+    {
+        return make(transform_point(inv_m, o), transform_vector(inv_m, d));
+    }
+};
+
+// ------------------------------------------------------------------ boundingbox.rs
+struct AABB
+{
+    V3 mn, mx;
+    static AABB identity() { return AABB{splat(INF), splat(-INF)}; }             // boundingbox.rs:59-65
+    AABB transform(const Affine& m) const                                        // boundingbox.rs:51-57 (corner-only)
+    {
+        V3 a = transform_point(m, mn), b = transform_point(m, mx);
+        return AABB{vmin(a, b), vmax(a, b)};
+    }
+    float surface_area() const                                                   // boundingbox.rs:90-95
+    {
+        V3 v = mx - mn;
+        return 2.0f * dot(v, V3{v.z, v.x, v.y});
+    }
+    uint8_t longest_axis() const                                                 // boundingbox.rs:71-88
+    {
+        V3 l = mx - mn;
+        float m = max_element(l);
+        if (l.x == m) return 0;
+        if (l.y == m) return 1;
+        return 2;
+    }
+    bool intersect(const Ray& r, float t_max) const                              // boundingbox.rs:97-113
+    {
+        V3 t0 = (mn - r.o) * r.inv, t1 = (mx - r.o) * r.inv;
+        V3 tmin_v = splat(EPSILON), tmax_v = splat(t_max);
+        V3 t_smaller = vmin(vmax(t0, tmin_v), vmax(t1, tmin_v));
+        V3 t_bigger = vmax(vmin(t0, tmax_v), vmin(t1, tmax_v));
+        return max_element(t_smaller) <= min_element(t_bigger);
+    }
+    bool intersect_t(const Ray& r, float t_max, float* t_out) const              // boundingbox.rs:115-131
+    {
+        V3 t0 = (mn - r.o) * r.inv, t1 = (mx - r.o) * r.inv;
+        V3 tmin_v = splat(EPSILON), tmax_v = splat(t_max);
+        V3 t_smaller = vmin(vmax(t0, tmin_v), vmax(t1, tmin_v));
+        V3 t_bigger = vmax(vmin(t0, tmax_v), vmin(t1, tmax_v));
+        float t = max_element(t_smaller);
+        *t_out = t;
+        return t <= min_element(t_bigger);
+    }
+};
+AABB surrounding_box(const AABB& a, const AABB& b) { return AABB{vmin(a.mn, b.mn), vmax(a.mx, b.mx)}; } // boundingbox.rs:134-139
+
+// ------------------------------------------------------------------ model.rs:5-11
+struct HitInfo
+{
+    V3 normal;
+    float u, v, t;
+    bool front_facing;
+};
+
+// ------------------------------------------------------------------ primitive.rs
+struct Triangle
+{
+    M3 positions, normals;
+    V4 n0, n1, n2;
+
+    static Triangle make(const V3 p[3], const V3 n[3])                           // primitive.rs:31-54
+    {
+        V3 ab = p[1] - p[0], ac = p[2] - p[0];
+        V3 n0 = cross(ab, ac);
+        float d0 = dot(n0, p[0]);
+        float scale = length_squared(n0);
+        V3 n1 = cross(ac, n0) / scale;
+        float d1 = -dot(n1, p[0]);
+        V3 n2 = cross(n0, ab) / scale;
+        float d2 = -dot(n2, p[0]);
+        Triangle t;
+        t.positions = M3{p[0], p[1], p[2]};
+        t.normals = M3{n[0], n[1], n[2]};
+        t.n0 = V4{n0.x, n0.y, n0.z, d0};
+        t.n1 = V4{n1.x, n1.y, n1.z, d1};
+        t.n2 = V4{n2.x, n2.y, n2.z, d2};
+        return t;
+    }
+    V3 get_normal(float u, float v) const                                        // primitive.rs:57-63
+    {
+        float w = 1.0f - u - v;
+        return normalize(mul(normals, V3{w, u, v}));
+    }
+    V3 get_position(float u, float v) const                                      // primitive.rs:66-70
+    {
+        float w = 1.0f - u - v;
+        return mul(positions, V3{w, u, v});
+    }
+    void random_point(Rng& rng, V3* p, V3* n) const                              // primitive.rs:77-91
+    {
+        float u = rng.next_f32();
+        float v = rng.next_f32();
+        if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+        *p = get_position(u, v);
+        *n = get_normal(u, v);
+    }
+    float area() const { return 0.5f * length(V3{n0.x, n0.y, n0.z}); }           // primitive.rs:94
+    AABB create_bounding_box() const                                             // primitive.rs:97-103
+    {
+        V3 mn = vmin(vmin(positions.c0, positions.c1), positions.c2);
+        V3 mx = vmax(vmax(positions.c0, positions.c1), positions.c2);
+        return AABB{mn, mx};
+    }
+    // Havel-Herout, primitive.rs:117-144.  Returns (t*det, u*det, v*det, det).
+    bool intersect_naive(V3 origin, V3 direction, float t_min, float t_max, V4* out) const
+    {
+        float det = dot(direction, V3{n0.x, n0.y, n0.z});
+        float td = -dot4(V4{origin.x, origin.y, origin.z, -1.0f}, n0);
+        if (signum_differs(td - det * t_min, det * t_max - td)) return false;
+        V3 p3 = det * origin + td * direction;
+        V4 p{p3.x, p3.y, p3.z, det};
+        float ud = dot4(p, n1);
+        if (signum_differs(ud, det - ud)) return false;
+        float vd = dot4(p, n2);
+        if (signum_differs(vd, det - ud - vd)) return false;
+        *out = V4{td, ud, vd, det};
+        return true;
+    }
+    bool intersect(const Ray& ray, float t_max, float t_estimate, HitInfo* hi) const // primitive.rs:147-178
+    {
+        V3 moved = ray.at(t_estimate);
+        V4 tuvd;
+        if (!intersect_naive(moved, ray.d, EPSILON - t_estimate, t_max - t_estimate, &tuvd)) return false;
+        V3 q = V3{tuvd.x, tuvd.y, tuvd.z} / tuvd.w;
+        V3 n = get_normal(q.y, q.z);
+        bool face_forward = dot(ray.d, n) < 0.0f;
+        hi->normal = face_forward ? n : -n;
+        hi->u = q.y;
+        hi->v = q.z;
+        hi->t = q.x + t_estimate;
+        hi->front_facing = face_forward;
+        return true;
+    }
+    bool intersect_bool(const Ray& ray, float t_max, float t_estimate) const      // primitive.rs:181-189
+    {
+        V3 moved = ray.at(t_estimate);
+        V4 tuvd;
+        return intersect_naive(moved, ray.d, EPSILON - t_estimate, t_max - t_estimate, &tuvd);
+    }
+};
+
+// ------------------------------------------------------------------ volume.rs
+struct Volume
+{
+    bool has_absorption = false, has_scatter = false;
+    V3 absorption{0, 0, 0}; // absorption * k                                   volume.rs:112
+    float c = 0, g = 0;     // g clamped to +-0.999                             volume.rs:27
+    V3 get_transmission(float dist) const                                        // volume.rs:113
+    {
+        V3 e = -absorption * dist;
+        return V3{det_exp(e.x), det_exp(e.y), det_exp(e.z)};
+    }
+    V3 scatter_direction(Rng& rng, V3 incoming) const                            // volume.rs:32-60
+    {
+        float u0 = rng.next_f32();
+        float u1 = rng.next_f32();
+        float phi = 2.0f * PI_F * u0;
+        float z;
+        if (g == 0.0f) { z = 1.0f - 2.0f * u1; }
+        else
+        {
+            float x = (1.0f - g * g) / (1.0f + g * (1.0f - 2.0f * u1));
+            z = (1.0f + g * g - x * x) / (2.0f * g);
+        }
+        float sine, cosine;
+        det_sincos(phi, &sine, &cosine);
+        float r = std::sqrt(1.0f - z * z);
+        float x = r * cosine, y = r * sine;
+        return mul(generate_onb(-incoming), V3{x, y, z});
+    }
+    // volume.rs:83-97 (scatter_pdf result is discarded by the integrator's `(t, dir, _)` pattern)
+    bool scatter(Rng& rng, V3 incoming, float t_max, float* t_out, V3* dir) const
+    {
+        float t = -det_ln(rng.next_f32()) / c;
+        if (t > t_max) return false;
+        *dir = scatter_direction(rng, incoming);
+        *t_out = t;
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------ material.rs
+struct BsdfPdf { V3 bsdf; float pdf; };
+
+V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }                      // utility.rs:21
+V3 refract(V3 i, V3 n, float eta)                                                // utility.rs:23-36
+{
+    float n_dot_i = dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - n_dot_i * n_dot_i);
+    if (k <= 0.0f) return splat(NAN);
+    return eta * i - (eta * n_dot_i + std::sqrt(k)) * n;
+}
+V3 random_cosine_vector(Rng& rng)                                                // utility.rs:7-19
+{
+    float r = std::sqrt(rng.next_f32());
+    float z = std::sqrt(1.0f - r * r);
+    float phi = TAU_F * rng.next_f32();
+    float s, c;
+    det_sincos(phi, &s, &c);
+    return V3{c * r, s * r, z};
+}
+M3 generate_onb_ggx(V3 v)                                                        // onb.rs:9-27
+{
+    if (v.z > 0.99999f) return M3{V3{1, 0, 0}, V3{-0.0f, -1.0f, -0.0f}, V3{0, 0, 1}};
+    V3 t1 = normalize(cross(v, V3{0, 0, 1}));
+    V3 t2 = cross(t1, v);
+    return M3{t1, t2, v};
+}
+
+struct Material
+{
+    int kind = PTO_LAMBERTIAN;
+    V3 colour{0, 0, 0}; // albedo / emitted / colour
+    float a = 0;        // GGX alpha = clamp(roughness^2, 1e-4, 0.9999)            material.rs:294,309
+    float ior = 1;
+    bool has_volume = false;
+    Volume volume;
+
+    bool is_delta() const { return kind == PTO_SPECULAR || kind == PTO_DIELECTRIC; }   // material.rs:151,494
+    bool is_emissive() const { return kind == PTO_EMISSIVE; }                           // material.rs:131
+    V3 get_emitted() const { return kind == PTO_EMISSIVE ? colour : V3{0, 0, 0}; }      // material.rs:51,135
+    float get_weakening(V3 wo, V3 n) const { return is_delta() ? 1.0f : std::fabs(dot(wo, n)); } // material.rs:67-77
+    const Volume* get_volume() const                                                    // material.rs:62,452-459,529
+    {
+        return ((kind == PTO_GGX_DIELECTRIC || kind == PTO_DIELECTRIC) && has_volume) ? &volume : nullptr;
+    }
+
+    // ---- GGX helpers, material.rs:189-284
+    float ggx_d(V3 h) const
+    {
+        if (h.z <= 0.0f) return 0.0f;
+        float cosine_sq = h.z * h.z;
+        float tan_sq = std::sqrt(1.0f - cosine_sq) / cosine_sq; // as written at material.rs:197
+        float x = (a * a) + tan_sq;
+        return a * a / (PI_F * cosine_sq * cosine_sq * x * x);
+    }
+    static float ggx_f(float v_dot_h, float f0) { return mul_add(powi5(1.0f - v_dot_h), 1.0f - f0, f0); } // material.rs:205
+    static V3 ggx_f_vector(float v_dot_h, V3 f0)                                                            // material.rs:207
+    {
+        V3 one_minus{1.0f - f0.x, 1.0f - f0.y, 1.0f - f0.z};
+        return f0 + (one_minus * powi5(1.0f - v_dot_h));
+    }
+    float ggx_g1(V3 v, V3 h) const                                                                           // material.rs:210-221
+    {
+        if (v.z * dot(h, v) <= 0.0f) return 0.0f;
+        float tan_squared = powi_m2(v.z) - 1.0f;
+        return 2.0f / (1.0f + std::sqrt(1.0f + a * a * tan_squared));
+    }
+    float ggx_g(V3 wi, V3 wo, V3 h) const { return ggx_g1(wi, h) * ggx_g1(wo, h); }                           // material.rs:224
+    float ggx_g_uncorrelated(V3 wi, V3 wo) const                                                             // material.rs:227-244
+    {
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+        float a_squared = a * a;
+        float x = 2.0f * wi.z * wo.z;
+        float y = 1.0f - a_squared;
+        float z = wo.z * det_hypot(a, wi.z * std::sqrt(y));
+        float w = wi.z * det_hypot(a, wo.z * std::sqrt(y));
+        return x / (z + w);
+    }
+    V3 ggx_half_vector(Rng& rng, V3 incoming, V3 normal) const                                               // material.rs:248-284
+    {
+        M3 onb_a = generate_onb(normal);
+        V3 _v = mul(transpose(onb_a), -incoming);
+        V3 v = normalize(_v * V3{a, a, 1.0f});
+        M3 onb_b = generate_onb_ggx(v);
+        float u1 = rng.next_f32();
+        float u2 = rng.next_f32();
+        float _a = 1.0f / (1.0f + v.z);
+        bool condition = u2 < _a;
+        float r = rs_min(std::sqrt(u1), 0.9999f);
+        float phi = condition ? (PI_F * u2 / _a) : (PI_F + ((u2 - _a) / (1.0f - _a)) * PI_F);
+        float sn, cs;
+        det_sincos(phi, &sn, &cs);
+        float p1 = r * cs;
+        float p2 = r * sn * (condition ? 1.0f : v.z);
+        V3 _h = mul(onb_b, V3{p1, p2, std::sqrt(1.0f - p1 * p1 - p2 * p2)});
+        return mul(onb_a, normalize(_h * V3{a, a, 1.0f}));
+    }
+    static float dielectric_f(float cosine, float eta)                                                       // material.rs:477-489
+    {
+        if (eta * eta * (1.0f - cosine * cosine) > 1.0f) return 1.0f;
+        float f0 = powi2((eta - 1.0f) / (eta + 1.0f));
+        return mul_add(powi5(1.0f - cosine), 1.0f - f0, f0);
+    }
+
+    V3 scatter_direction(Rng& rng, V3 incoming, V3 normal, bool front_facing) const
+    {
+        switch (kind)
+        {
+        case PTO_LAMBERTIAN: return mul(generate_onb(normal), random_cosine_vector(rng));   // material.rs:104-107
+        case PTO_EMISSIVE: return V3{0, 0, 0};                                               // material.rs:133
+        case PTO_SPECULAR: return reflect(incoming, normal);                                 // material.rs:153
+        case PTO_GGX_METAL:                                                                  // material.rs:317-325
+        {
+            V3 h = ggx_half_vector(rng, incoming, normal);
+            return reflect(incoming, h);
+        }
+        case PTO_GGX_DIELECTRIC:                                                             // material.rs:326-346
+        {
+            V3 h = ggx_half_vector(rng, incoming, normal);
+            float eta = front_facing ? (1.0f / ior) : ior;
+            float f0 = powi2((eta - 1.0f) / (eta + 1.0f));
+            float f = ggx_f(-dot(incoming, h), f0);
+            V3 refracted = refract(incoming, h, eta);
+            bool ray_reflected = is_nan(refracted) || rng.next_f32() < f; // conditional draw, material.rs:335
+            return ray_reflected ? reflect(incoming, h) : refracted;
+        }
+        case PTO_DIELECTRIC:                                                                 // material.rs:496-509
+        {
+            float eta = front_facing ? (1.0f / ior) : ior;
+            float cosine = -dot(incoming, normal);
+            if (rng.next_f32() < dielectric_f(cosine, eta)) return reflect(incoming, normal);
+            return refract(incoming, normal, eta);
+        }
+        }
+        return V3{0, 0, 0};
+    }
+
+    BsdfPdf get_bsdf_pdf(V3 incoming, V3 outgoing, const HitInfo& hi) const
+    {
+        switch (kind)
+        {
+        case PTO_LAMBERTIAN:                                                                 // material.rs:109-115
+        {
+            float cosine = dot(outgoing, hi.normal);
+            return BsdfPdf{colour * FRAC_1_PI, cosine * FRAC_1_PI};
+        }
+        case PTO_EMISSIVE: return BsdfPdf{colour, 1.0f};                                     // material.rs:134
+        case PTO_SPECULAR: return BsdfPdf{colour, 1.0f};                                     // material.rs:155
+        case PTO_DIELECTRIC:                                                                 // material.rs:511-527
+        {
+            float cosine = -dot(incoming, outgoing);
+            float eta = hi.front_facing ? (1.0f / ior) : ior;
+            float f = dielectric_f(cosine, eta);
+            if (dot(outgoing, hi.normal) > 0.0f) return BsdfPdf{splat(f), f};
+            float bsdf = (1.0f - f) / (eta * eta);
+            return BsdfPdf{colour * bsdf, 1.0f - f};
+        }
+        case PTO_GGX_METAL:
+        case PTO_GGX_DIELECTRIC:                                                             // material.rs:349-450
+        {
+            const bool transmissive = kind == PTO_GGX_DIELECTRIC;
+            M3 onb_inv = transpose(generate_onb(hi.normal));
+            V3 wi = mul(onb_inv, outgoing);
+            V3 wo = mul(onb_inv, incoming);
+            bool ray_transmitted = wi.z < 0.0f;
+            V3 h;
+            if (transmissive && ray_transmitted)
+            {
+                float eta = hi.front_facing ? ior : (1.0f / ior);
+                V3 _h = normalize(eta * wi + wo);
+                h = _h * rs_signum(_h.z);
+            }
+            else { h = normalize(wi + wo); }
+            float i_dot_h = dot(wi, h), o_dot_h = dot(wo, h);
+            float d = ggx_d(h);
+            float f, g;
+            if (!transmissive) { f = 1.0f; g = ggx_g_uncorrelated(wi, wo); }
+            else
+            {
+                float eta = hi.front_facing ? ior : (1.0f / ior);
+                float f0 = powi2((eta - 1.0f) / (eta + 1.0f));
+                f = ggx_f(std::fabs(i_dot_h), f0);
+                g = ggx_g(wi, wo, h);
+            }
+            if (ray_transmitted)
+            {
+                if (!transmissive) return BsdfPdf{V3{0, 0, 0}, 0.0f};                        // BsdfPdf::invalid()
+                float eta = hi.front_facing ? ior : (1.0f / ior);
+                float x = std::fabs(i_dot_h * o_dot_h);
+                float y = std::fabs(wi.z * wo.z);
+                float z = (1.0f - f) * g * d;
+                float w = (eta * i_dot_h) + o_dot_h;
+                float btdf = (x * z) / (y * w * w);
+                float ja = std::fabs(o_dot_h), jb = w;
+                float jacobian = ja / (jb * jb);
+                float pdf = d * (1.0f - f) * std::fabs(h.z) * jacobian;
+                return BsdfPdf{colour * btdf * eta * eta, pdf};
+            }
+            float brdf = f * g * d / (4.0f * std::fabs(wi.z * wo.z));
+            float jacobian = 1.0f / (4.0f * std::fabs(o_dot_h));
+            float pdf = d * h.z * f * jacobian;
+            V3 tint = transmissive ? V3{1, 1, 1} : ggx_f_vector(std::fabs(i_dot_h), colour);
+            return BsdfPdf{brdf * tint, pdf};
+        }
+        }
+        return BsdfPdf{V3{0, 0, 0}, 0.0f};
+    }
+};
+
+// ------------------------------------------------------------------ blas_bvh.rs
+const size_t DESIRED_BINS = 64;       // blas_bvh.rs:13
+const float TRAVERSAL_COST = 1.0f;    // blas_bvh.rs:15
+const float INTERSECTION_COST = 2.0f; // blas_bvh.rs:16
+
+struct PrimitiveInfo { AABB box; uint32_t id; };
+AABB boxes_union(const PrimitiveInfo* p, size_t n)                                // blas_bvh.rs:28-33
+{
+    AABB a = AABB::identity();
+    for (size_t i = 0; i < n; ++i) a = surrounding_box(a, p[i].box);
+    return a;
+}
+enum { NODE_BRANCH = 0, NODE_LEAF_SINGLE = 1, NODE_LEAF = 2 };
+struct BLASNode
+{
+    AABB box;
+    int type;
+    uint32_t left = 0, right = 0, prim = 0;
+    std::vector<uint32_t> prims;
+};
+
+uint32_t generate_blas(std::vector<BLASNode>& arena, PrimitiveInfo* info, size_t span, uint8_t last_split_axis) // blas_bvh.rs:62-136
+{
+    if (span == 1)
+    {
+        BLASNode n;
+        n.box = info[0].box;
+        n.type = NODE_LEAF_SINGLE;
+        n.prim = info[0].id;
+        arena.push_back(n);
+        return (uint32_t)arena.size() - 1;
+    }
+    AABB bb = boxes_union(info, span);
+    float bb_sa = bb.surface_area();
+    uint8_t split_axis = bb.longest_axis();
+    if (split_axis != last_split_axis)
+    {
+        // glidesort::sort_by = stable sort; comparator = total_cmp on minimum[axis] (boundingbox.rs:67)
+        std::stable_sort(info, info + span, [split_axis](const PrimitiveInfo& a, const PrimitiveInfo& b) {
+            const float* pa = &a.box.mn.x;
+            const float* pb = &b.box.mn.x;
+            return total_key(pa[split_axis]) < total_key(pb[split_axis]);
+        });
+    }
+    size_t bin_size = std::max<size_t>(span / DESIRED_BINS, 1);
+    size_t num_bins = (span / bin_size) - 1;
+    size_t best_split = 0;
+    float best_sah = 0;
+    bool have = false;
+    for (size_t i = 0; i < num_bins; ++i)
+    {
+        size_t j = (i + 1) * bin_size;
+        AABB l = boxes_union(info, j), r = boxes_union(info + j, span - j);
+        float sah = TRAVERSAL_COST + (((float)j) * l.surface_area() + ((float)(span - j)) * r.surface_area()) * INTERSECTION_COST / bb_sa;
+        // Iterator::min_by keeps the FIRST of equal minima; ordering is f32::total_cmp
+        if (!have || total_key(sah) < total_key(best_sah)) { best_sah = sah; best_split = j; have = true; }
+    }
+    float no_split_sah = INTERSECTION_COST * (float)span;
+    if (no_split_sah < best_sah)
+    {
+        BLASNode n;
+        n.box = bb;
+        n.type = NODE_LEAF;
+        for (size_t i = 0; i < span; ++i) n.prims.push_back(info[i].id);
+        arena.push_back(n);
+        return (uint32_t)arena.size() - 1;
+    }
+    uint32_t left = generate_blas(arena, info, best_split, split_axis);
+    uint32_t right = generate_blas(arena, info + best_split, span - best_split, split_axis);
+    BLASNode n;
+    n.box = bb;
+    n.type = NODE_BRANCH;
+    n.left = left;
+    n.right = right;
+    arena.push_back(n);
+    return (uint32_t)arena.size() - 1;
+}
+
+// ------------------------------------------------------------------ blas.rs
+struct StackEntry { uint32_t id; float t; };
+struct Scratch
+{
+    std::vector<StackEntry> tlas_stack, blas_stack;
+    std::vector<uint32_t> tlas_ids, blas_ids;
+    Counters* ctr = nullptr;
+};
+
+// blas.rs:133-162: test both children, push far first; on a tie (t_l >= t_r) left is pushed first.
+template <class Node>
+void push_to_stack(const Ray& r, float t_max, std::vector<StackEntry>& stack, const std::vector<Node>& arena, uint32_t left,
+                   uint32_t right, Counters* ctr)
+{
+    float tl, tr;
+    bool il = arena[left].box.intersect_t(r, t_max, &tl);
+    bool ir = arena[right].box.intersect_t(r, t_max, &tr);
+    ctr->node();
+    ctr->node();
+    if (il && ir)
+    {
+        if (tl < tr) { stack.push_back({right, tr}); stack.push_back({left, tl}); }
+        else { stack.push_back({left, tl}); stack.push_back({right, tr}); }
+    }
+    else if (il) { stack.push_back({left, tl}); }
+    else if (ir) { stack.push_back({right, tr}); }
+}
+
+struct BLAS
+{
+    std::vector<Triangle> primitives;
+    int material = 0;
+    uint32_t root = 0;
+    std::vector<BLASNode> nodes;
+
+    void build(const float* positions, const float* normals, uint32_t n_tris, int mat)   // blas.rs:174-201
+    {
+        material = mat;
+        primitives.reserve(n_tris);
+        for (uint32_t i = 0; i < n_tris; ++i)
+        {
+            V3 p[3], n[3];
+            for (int k = 0; k < 3; ++k)
+            {
+                p[k] = V3{positions[(i * 3 + k) * 3 + 0], positions[(i * 3 + k) * 3 + 1], positions[(i * 3 + k) * 3 + 2]};
+                n[k] = V3{normals[(i * 3 + k) * 3 + 0], normals[(i * 3 + k) * 3 + 1], normals[(i * 3 + k) * 3 + 2]};
+            }
+            primitives.push_back(Triangle::make(p, n));
+        }
+        std::vector<PrimitiveInfo> info(n_tris);
+        for (uint32_t i = 0; i < n_tris; ++i) info[i] = PrimitiveInfo{primitives[i].create_bounding_box(), i};
+        root = generate_blas(nodes, info.data(), info.size(), 4);
+    }
+
+    bool intersect(Scratch& sc, const Ray& r, float t_max, HitInfo* out, uint32_t* prim_out) const // blas.rs:214-256
+    {
+        auto& stack = sc.blas_stack;
+        stack.clear();
+        stack.push_back({root, 0.0f}); // root pushed without a box test
+        bool found = false;
+        while (!stack.empty())
+        {
+            StackEntry e = stack.back();
+            stack.pop_back();
+            if (e.t > t_max) continue;
+            const BLASNode& n = nodes[e.id];
+            if (n.type == NODE_BRANCH) { push_to_stack(r, t_max, stack, nodes, n.left, n.right, sc.ctr); }
+            else if (n.type == NODE_LEAF_SINGLE)
+            {
+                HitInfo hi;
+                sc.ctr->tri();
+                if (primitives[n.prim].intersect(r, t_max, e.t, &hi)) { t_max = hi.t; *out = hi; *prim_out = n.prim; found = true; }
+            }
+            else
+            {
+                for (uint32_t id : n.prims)
+                {
+                    HitInfo hi;
+                    sc.ctr->tri();
+                    if (primitives[id].intersect(r, t_max, e.t, &hi)) { t_max = hi.t; *out = hi; *prim_out = id; found = true; }
+                }
+            }
+        }
+        return found;
+    }
+    bool any_intersect(Scratch& sc, const Ray& r, float t_max) const                      // blas.rs:257-294
+    {
+        auto& stack = sc.blas_ids;
+        stack.clear();
+        stack.push_back(root);
+        while (!stack.empty())
+        {
+            uint32_t cur = stack.back();
+            stack.pop_back();
+            float t_enter;
+            sc.ctr->node();
+            if (!nodes[cur].box.intersect_t(r, t_max, &t_enter)) continue;
+            const BLASNode& n = nodes[cur];
+            if (n.type == NODE_BRANCH) { stack.push_back(n.left); stack.push_back(n.right); }
+            else if (n.type == NODE_LEAF_SINGLE)
+            {
+                sc.ctr->tri();
+                if (primitives[n.prim].intersect_bool(r, t_max, t_enter)) return true;
+            }
+            else
+            {
+                for (uint32_t id : n.prims)
+                {
+                    sc.ctr->tri();
+                    if (primitives[id].intersect_bool(r, t_max, t_enter)) return true;
+                }
+            }
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------ tlas_bvh.rs / tlas.rs
+struct TLASNode
+{
+    AABB box;
+    bool leaf = false;
+    uint32_t blas = 0, instance = 0;
+    Affine matrix, inv_matrix;
+    uint32_t left = 0, right = 0;
+};
+
+struct ModelDesc
+{
+    std::vector<float> positions, normals;
+    uint32_t n_tris;
+    int material;
+    std::vector<Affine> matrices;
+};
+
+struct TLAS
+{
+    std::vector<BLAS> blas;
+    std::vector<TLASNode> nodes;
+    uint32_t root = 0;
+    bool empty = true;
+
+    static size_t find_best_match(const std::vector<TLASNode>& arena, const std::vector<uint32_t>& list, size_t a_index) // tlas_bvh.rs:56-83
+    {
+        const AABB& a = arena[list[a_index]].box;
+        float best_sa = INF;
+        size_t best_index = SIZE_MAX;
+        for (size_t i = 0; i < list.size(); ++i)
+        {
+            if (i == a_index) continue;
+            float sa = surrounding_box(a, arena[list[i]].box).surface_area();
+            if (sa < best_sa) { best_index = i; best_sa = sa; }
+        }
+        return best_index;
+    }
+    static uint32_t swap_remove(std::vector<uint32_t>& v, size_t i)
+    {
+        uint32_t x = v[i];
+        v[i] = v.back();
+        v.pop_back();
+        return x;
+    }
+    void build(const std::vector<const ModelDesc*>& models)                               // tlas.rs:24-53 + tlas_bvh.rs:85-138
+    {
+        blas.resize(models.size());
+        for (size_t i = 0; i < models.size(); ++i)
+            blas[i].build(models[i]->positions.data(), models[i]->normals.data(), models[i]->n_tris, models[i]->material);
+        std::vector<uint32_t> list;
+        for (size_t i = 0; i < models.size(); ++i)
+        {
+            const AABB bb = blas[i].nodes[blas[i].root].box;
+            for (const Affine& m : models[i]->matrices)
+            {
+                TLASNode n;
+                n.box = bb.transform(m);
+                n.leaf = true;
+                n.blas = (uint32_t)i;
+                n.instance = (uint32_t)nodes.size();
+                n.matrix = m;
+                n.inv_matrix = inverse(m);
+                nodes.push_back(n);
+                list.push_back((uint32_t)nodes.size() - 1);
+            }
+        }
+        empty = list.empty();
+        if (empty) return;
+        size_t a = 0;
+        size_t b = list.size() > 1 ? find_best_match(nodes, list, a) : SIZE_MAX;
+        while (list.size() > 1)
+        {
+            size_t c = find_best_match(nodes, list, b);
+            if (a == c)
+            {
+                uint32_t n1, n2;
+                if (a > b) { n1 = swap_remove(list, a); n2 = swap_remove(list, b); }
+                else { n1 = swap_remove(list, b); n2 = swap_remove(list, a); }
+                a = list.size();
+                TLASNode n;
+                n.box = surrounding_box(nodes[n1].box, nodes[n2].box);
+                n.leaf = false;
+                n.left = n1;
+                n.right = n2;
+                nodes.push_back(n);
+                list.push_back((uint32_t)nodes.size() - 1);
+                b = list.size() > 1 ? find_best_match(nodes, list, a) : SIZE_MAX;
+            }
+            else { a = b; b = c; }
+        }
+        root = list[0];
+    }
+
+    // tlas.rs:66-110
+    bool intersect(Scratch& sc, const Ray& r, float t_max, HitInfo* out, uint32_t* blas_out, uint32_t* prim_out, uint32_t* inst_out) const
+    {
+        if (empty) return false;
+        sc.ctr->node();
+        if (!nodes[root].box.intersect(r, t_max)) return false;
+        auto& stack = sc.tlas_stack;
+        stack.clear();
+        stack.push_back({root, 0.0f});
+        bool found = false;
+        HitInfo best{};
+        uint32_t best_node = 0, best_prim = 0;
+        while (!stack.empty())
+        {
+            StackEntry e = stack.back();
+            stack.pop_back();
+            if (e.t > t_max) continue;
+            const TLASNode& n = nodes[e.id];
+            if (!n.leaf) { push_to_stack(r, t_max, stack, nodes, n.left, n.right, sc.ctr); }
+            else
+            {
+                Ray ray = r.transform(n.inv_matrix);
+                HitInfo hi;
+                uint32_t prim;
+                if (blas[n.blas].intersect(sc, ray, t_max, &hi, &prim))
+                {
+                    t_max = hi.t;
+                    best = hi;
+                    best_node = e.id;
+                    best_prim = prim;
+                    found = true;
+                }
+            }
+        }
+        if (!found) return false;
+        best.normal = transform_vector(nodes[best_node].matrix, best.normal); // deferred normal transform, tlas.rs:105
+        *out = best;
+        *blas_out = nodes[best_node].blas;
+        *prim_out = best_prim;
+        *inst_out = nodes[best_node].instance;
+        return true;
+    }
+    bool any_intersect(Scratch& sc, const Ray& r, float t_max) const                      // tlas.rs:111-144
+    {
+        if (empty) return false;
+        auto& stack = sc.tlas_ids;
+        stack.clear();
+        stack.push_back(root);
+        while (!stack.empty())
+        {
+            uint32_t cur = stack.back();
+            stack.pop_back();
+            sc.ctr->node();
+            if (!nodes[cur].box.intersect(r, t_max)) continue;
+            const TLASNode& n = nodes[cur];
+            if (!n.leaf) { stack.push_back(n.left); stack.push_back(n.right); }
+            else
+            {
+                Ray ray = r.transform(n.inv_matrix);
+                if (blas[n.blas].any_intersect(sc, ray, t_max)) return true;
+            }
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------ light_sampler.rs / scene.rs
+struct LightItem { uint32_t blas, prim; float pdf; };
+struct LightSampler
+{
+    std::vector<LightItem> lights;
+    std::vector<float> cdf;
+    float max = 0;
+    void build(const TLAS& lights_tlas, const std::vector<Material>& mats)                // tlas.rs:55-64, blas.rs:203-212, light_sampler.rs:41-61
+    {
+        std::vector<LightItem> data;
+        for (size_t b = 0; b < lights_tlas.blas.size(); ++b)
+            for (size_t p = 0; p < lights_tlas.blas[b].primitives.size(); ++p)
+            {
+                float w = lights_tlas.blas[b].primitives[p].area() * length(mats[lights_tlas.blas[b].material].get_emitted());
+                data.push_back({(uint32_t)b, (uint32_t)p, w});
+            }
+        float m = 0.0f;
+        for (auto& d : data) m = m + d.pdf;
+        max = m;
+        float state = 0.0f;
+        for (auto& d : data)
+        {
+            lights.push_back({d.blas, d.prim, d.pdf / max});
+            state += lights.back().pdf;
+            cdf.push_back(state);
+        }
+    }
+    // light_sampler.rs:31-37: binary_search_by(total_cmp) -> Ok(i) | Err(i); for a strictly increasing cdf both equal the number
+    // of entries below x.  Clamped to len-1 (deviation B-8).
+    const LightItem& sample(Rng& rng) const
+    {
+        float x = rng.next_f32();
+        size_t idx = 0;
+        while (idx < cdf.size() && total_key(cdf[idx]) < total_key(x)) ++idx;
+        if (idx >= lights.size()) idx = lights.size() - 1;
+        return lights[idx];
+    }
+    float get_sample_pdf(const Triangle& tri, const Material& m) const { return tri.area() * length(m.get_emitted()) / max; } // light_sampler.rs:39
+};
+
+// ------------------------------------------------------------------ sampling.rs
+const uint32_t DIRECTIONS[32] = { // sampling.rs:4-8
+    0x80000000, 0xc0000000, 0xa0000000, 0xf0000000, 0x88000000, 0xcc000000, 0xaa000000, 0xff000000, 0x80800000, 0xc0c00000, 0xa0a00000,
+    0xf0f00000, 0x88880000, 0xcccc0000, 0xaaaa0000, 0xffff0000, 0x80008000, 0xc000c000, 0xa000a000, 0xf000f000, 0x88008800, 0xcc00cc00,
+    0xaa00aa00, 0xff00ff00, 0x80808080, 0xc0c0c0c0, 0xa0a0a0a0, 0xf0f0f0f0, 0x88888888, 0xcccccccc, 0xaaaaaaaa, 0xffffffff,
+};
+uint32_t reverse_bits(uint32_t x)
+{
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+    return x;
+}
+uint32_t sobol_dim1(uint32_t index)                                               // sampling.rs:24-30
+{
+    uint32_t x = 0;
+    for (int bit = 0; bit < 32; ++bit) x ^= ((index >> bit) & 1u) * DIRECTIONS[bit];
+    return x;
+}
+uint32_t lk_hash(uint32_t x, uint32_t seed)                                       // sampling.rs:53-68
+{
+    x ^= x * 0x3d20adeau;
+    x += seed;
+    x *= (seed >> 16) | 1u;
+    x ^= x * 0x05526c56u;
+    x ^= x * 0x53a22864u;
+    return x;
+}
+uint32_t scramble_base2(uint32_t x, uint32_t seed) { return reverse_bits(lk_hash(reverse_bits(x), seed)); } // sampling.rs:71
+uint32_t low_bias_hash(uint32_t x)                                                // sampling.rs:76-91
+{
+    x ^= x >> 16;
+    x *= 0x21f0aaadu;
+    x ^= x >> 15;
+    x *= 0xd35a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+// sampling.rs:97-114; table entry i = (reverse_bits(i), sobol(i)) (sampling.rs:38-45) is recomputed instead of stored
+void ss_sobol_raw(uint32_t n_points, uint32_t index, uint32_t seed, uint32_t out[3])
+{
+    uint32_t x_seed = low_bias_hash(seed);
+    uint32_t y_seed = low_bias_hash(seed + 1u);
+    uint32_t shuffle_seed = low_bias_hash(seed + 2u);
+    uint32_t shuffled_index = scramble_base2(index, shuffle_seed);
+    uint32_t slot = shuffled_index % n_points;
+    out[0] = shuffled_index;
+    out[1] = scramble_base2(reverse_bits(slot), x_seed);
+    out[2] = scramble_base2(sobol_dim1(slot), y_seed);
+}
+void ss_sobol(uint32_t n_points, uint32_t index, uint32_t seed, float out[2])
+{
+    uint32_t raw[3];
+    ss_sobol_raw(n_points, index, seed, raw);
+    out[0] = (float)raw[1] / 4294967296.0f; // u32::MAX as f32 == 2^32
+    out[1] = (float)raw[2] / 4294967296.0f;
+}
+
+// ------------------------------------------------------------------ camera.rs
+struct M4 { V4 c[4]; };
+V4 mul4(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+V4 add4(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+V4 mulv(V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+V4 subv(V4 a, V4 b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+V4 mat4_mul_vec(const M4& m, V4 v) // glam Mat4::mul_vec4
+{
+    V4 res = mul4(m.c[0], v.x);
+    res = add4(res, mul4(m.c[1], v.y));
+    res = add4(res, mul4(m.c[2], v.z));
+    res = add4(res, mul4(m.c[3], v.w));
+    return res;
+}
+M4 mat4_mul(const M4& a, const M4& b) { return M4{{mat4_mul_vec(a, b.c[0]), mat4_mul_vec(a, b.c[1]), mat4_mul_vec(a, b.c[2]), mat4_mul_vec(a, b.c[3])}}; }
+M4 mat4_inverse(const M4& s) // glam Mat4::inverse (scalar form of the cofactor expansion)
+{
+    float m00 = s.c[0].x, m01 = s.c[0].y, m02 = s.c[0].z, m03 = s.c[0].w;
+    float m10 = s.c[1].x, m11 = s.c[1].y, m12 = s.c[1].z, m13 = s.c[1].w;
+    float m20 = s.c[2].x, m21 = s.c[2].y, m22 = s.c[2].z, m23 = s.c[2].w;
+    float m30 = s.c[3].x, m31 = s.c[3].y, m32 = s.c[3].z, m33 = s.c[3].w;
+    float coef00 = m22 * m33 - m32 * m23, coef02 = m12 * m33 - m32 * m13, coef03 = m12 * m23 - m22 * m13;
+    float coef04 = m21 * m33 - m31 * m23, coef06 = m11 * m33 - m31 * m13, coef07 = m11 * m23 - m21 * m13;
+    float coef08 = m21 * m32 - m31 * m22, coef10 = m11 * m32 - m31 * m12, coef11 = m11 * m22 - m21 * m12;
+    float coef12 = m20 * m33 - m30 * m23, coef14 = m10 * m33 - m30 * m13, coef15 = m10 * m23 - m20 * m13;
+    float coef16 = m20 * m32 - m30 * m22, coef18 = m10 * m32 - m30 * m12, coef19 = m10 * m22 - m20 * m12;
+    float coef20 = m20 * m31 - m30 * m21, coef22 = m10 * m31 - m30 * m11, coef23 = m10 * m21 - m20 * m11;
+    V4 fac0{coef00, coef00, coef02, coef03}, fac1{coef04, coef04, coef06, coef07}, fac2{coef08, coef08, coef10, coef11};
+    V4 fac3{coef12, coef12, coef14, coef15}, fac4{coef16, coef16, coef18, coef19}, fac5{coef20, coef20, coef22, coef23};
+    V4 vec0{m10, m00, m00, m00}, vec1{m11, m01, m01, m01}, vec2{m12, m02, m02, m02}, vec3{m13, m03, m03, m03};
+    V4 inv0 = add4(subv(mulv(vec1, fac0), mulv(vec2, fac1)), mulv(vec3, fac2));
+    V4 inv1 = add4(subv(mulv(vec0, fac0), mulv(vec2, fac3)), mulv(vec3, fac4));
+    V4 inv2 = add4(subv(mulv(vec0, fac1), mulv(vec1, fac3)), mulv(vec3, fac5));
+    V4 inv3 = add4(subv(mulv(vec0, fac2), mulv(vec1, fac4)), mulv(vec2, fac5));
+    V4 sign_a{1.0f, -1.0f, 1.0f, -1.0f}, sign_b{-1.0f, 1.0f, -1.0f, 1.0f};
+    M4 inv{{mulv(inv0, sign_a), mulv(inv1, sign_b), mulv(inv2, sign_a), mulv(inv3, sign_b)}};
+    V4 col0{inv.c[0].x, inv.c[1].x, inv.c[2].x, inv.c[3].x};
+    V4 dot0 = mulv(s.c[0], col0);
+    float dot1 = dot0.x + dot0.y + dot0.z + dot0.w;
+    float rcp = 1.0f / dot1;
+    return M4{{mul4(inv.c[0], rcp), mul4(inv.c[1], rcp), mul4(inv.c[2], rcp), mul4(inv.c[3], rcp)}};
+}
+// glam scalar Vec3::normalize = self * length_recip (camera.rs:19 converts to glam::Vec3)
+V3 normalize_recip(V3 v) { float r = 1.0f / std::sqrt(dot(v, v)); return v * r; }
+
+struct Camera
+{
+    Affine matrix;    // camera-to-world
+    M4 inv_projection;
+    M4 ray_matrix;    // matrix * inv_projection (camera.rs:98), constant per frame
+    bool set = false;
+    void init(V3 origin, V3 target, float fov_deg, float aspect)                  // camera.rs:17-31
+    {
+        // Affine3A::look_at_rh(eye, center, up) = look_to_lh(eye, eye - center, up)
+        V3 up{0, 1, 0};
+        V3 f = normalize_recip(-(target - origin));
+        V3 s = normalize_recip(cross(up, f));
+        V3 u = cross(f, s);
+        Affine view{M3{V3{s.x, u.x, f.x}, V3{s.y, u.y, f.y}, V3{s.z, u.z, f.z}}, V3{-dot(s, origin), -dot(u, origin), -dot(f, origin)}};
+        matrix = inverse(view);
+        // Mat4::perspective_infinite_rh(fov.to_radians(), aspect, 1.0).inverse()
+        float fov = fov_deg * (PI_F / 180.0f);
+        float fl = 1.0f / det_tan(0.5f * fov);
+        M4 proj{{V4{fl / aspect, 0, 0, 0}, V4{0, fl, 0, 0}, V4{0, 0, -1.0f, -1.0f}, V4{0, 0, -1.0f, 0}}};
+        inv_projection = mat4_inverse(proj);
+        M4 m4{{V4{matrix.m.c0.x, matrix.m.c0.y, matrix.m.c0.z, 0}, V4{matrix.m.c1.x, matrix.m.c1.y, matrix.m.c1.z, 0},
+               V4{matrix.m.c2.x, matrix.m.c2.y, matrix.m.c2.z, 0}, V4{matrix.t.x, matrix.t.y, matrix.t.z, 1.0f}}};
+        ray_matrix = mat4_mul(m4, inv_projection);
+        set = true;
+    }
+    Ray create_ray(float s, float t) const                                        // camera.rs:94-105
+    {
+        V3 ndc{s * 2.0f - 1.0f, t * 2.0f - 1.0f, 0.0f};
+        // Mat4::project_point3
+        V4 res = mul4(ray_matrix.c[0], ndc.x);
+        res = add4(mul4(ray_matrix.c[1], ndc.y), res);
+        res = add4(mul4(ray_matrix.c[2], ndc.z), res);
+        res = add4(ray_matrix.c[3], res);
+        float rw = 1.0f / res.w;
+        V3 point{res.x * rw, res.y * rw, res.z * rw};
+        V3 dir = normalize(point - matrix.t);
+        return Ray::make(matrix.t, dir);
+    }
+};
+
+// ------------------------------------------------------------------ scene.rs
+struct Scene
+{
+    TLAS world, lights;
+    LightSampler light_sampler;
+    std::vector<Material> materials;
+    bool has_lights = false;
+};
+
+} // namespace
+
+struct pto_ctx
+{
+    std::vector<Material> materials;
+    std::vector<ModelDesc> models;
+    std::unique_ptr<Scene> scene;
+    Camera camera;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ integrator.rs
+const float MIN_PDF = 0.0f; // integrator.rs:10
+float mis_heuristic(float f, float g) { return powi2(f) / (powi2(f) + powi2(g)); } // integrator.rs:22, POWER = 2
+
+struct Tracer
+{
+    const Scene* scene;
+    Scratch sc;
+    Counters ctr;
+    Tracer(const Scene* s) : scene(s) { sc.ctr = &ctr; }
+    bool world_intersect(const Ray& r, float t_max, HitInfo* hi, uint32_t* blas, uint32_t* prim, uint32_t* inst)
+    {
+        ctr.c[0]++;
+        ctr.mode = 0;
+        return scene->world.intersect(sc, r, t_max, hi, blas, prim, inst);
+    }
+    bool world_any(const Ray& r, float t_max)
+    {
+        ctr.c[1]++;
+        ctr.mode = 1;
+        return scene->world.any_intersect(sc, r, t_max);
+    }
+    bool lights_intersect(const Ray& r, float t_max, HitInfo* hi, uint32_t* blas, uint32_t* prim, uint32_t* inst)
+    {
+        ctr.c[2]++;
+        ctr.mode = 2;
+        return scene->lights.intersect(sc, r, t_max, hi, blas, prim, inst);
+    }
+};
+
+V3 estimate_direct_explicit(Tracer& tr, Rng& rng, const Ray& incoming_ray, const HitInfo& hi, const Material& mat) // integrator.rs:25-74
+{
+    const Scene& scene = *tr.scene;
+    V3 incoming = -incoming_ray.d;
+    const LightItem& li = scene.light_sampler.sample(rng);                       // scene.rs:37-45
+    const BLAS& lb = scene.lights.blas[li.blas];
+    const Triangle& light = lb.primitives[li.prim];
+    const Material& light_material = scene.materials[lb.material];
+    float pdf = li.pdf;
+    V3 point, light_normal;
+    light.random_point(rng, &point, &light_normal);
+    V3 o = incoming_ray.at(hi.t);
+    V3 d = point - o;
+    float distance_squared = length_squared(d);
+    float distance = std::sqrt(distance_squared);
+    Ray outgoing = Ray::make(o, normalize(d));
+    if (dot(outgoing.d, hi.normal) > 0.0f && !tr.world_any(outgoing, (1.0f - EPSILON) * distance))
+    {
+        BsdfPdf bp = mat.get_bsdf_pdf(incoming, outgoing.d, hi);
+        float sample_pdf = pdf / light.area();
+        float cosine = std::fabs(dot(outgoing.d, light_normal));
+        float light_pdf = sample_pdf * (distance_squared / cosine);
+        float weight = mis_heuristic(light_pdf, bp.pdf);
+        return light_material.get_emitted() * weight * mat.get_weakening(outgoing.d, hi.normal) * bp.bsdf / light_pdf;
+    }
+    return V3{0, 0, 0};
+}
+
+V3 estimate_direct_bsdf(Tracer& tr, Rng& rng, const Ray& incoming_ray, const HitInfo& hi, const Material& mat) // integrator.rs:77-130
+{
+    const Scene& scene = *tr.scene;
+    V3 incoming = -incoming_ray.d;
+    Ray outgoing = Ray::make(incoming_ray.at(hi.t), mat.scatter_direction(rng, incoming_ray.d, hi.normal, hi.front_facing));
+    if (dot(outgoing.d, hi.normal) > 0.0f)
+    {
+        HitInfo lhi;
+        uint32_t lblas, lprim, linst;
+        if (tr.lights_intersect(outgoing, INF, &lhi, &lblas, &lprim, &linst))
+        {
+            if (!tr.world_any(outgoing, lhi.t * (1.0f - EPSILON)))
+            {
+                BsdfPdf bp = mat.get_bsdf_pdf(incoming, outgoing.d, hi);
+                if (bp.pdf > MIN_PDF)
+                {
+                    const BLAS& lb = scene.lights.blas[lblas];
+                    const Triangle& light = lb.primitives[lprim];
+                    const Material& light_material = scene.materials[lb.material];
+                    float sample_pdf = scene.light_sampler.get_sample_pdf(light, light_material) / light.area();
+                    float cosine = std::fabs(dot(outgoing.d, lhi.normal));
+                    float light_pdf = sample_pdf * (lhi.t * lhi.t / cosine);
+                    float weight = mis_heuristic(bp.pdf, light_pdf);
+                    return light_material.get_emitted() * weight * mat.get_weakening(outgoing.d, hi.normal) * bp.bsdf / bp.pdf;
+                }
+            }
+        }
+    }
+    return V3{0, 0, 0};
+}
+
+struct Sample { V4 colour; V4 position; uint8_t id; };
+
+// integrator.rs:143-281 (env is Err in this build: the PNG is not in the repository -> constant ambient branch :263-266)
+Sample integrate(Tracer& tr, Ray r, Rng& rng, uint32_t max_bounces, bool enable_nee)
+{
+    const Scene& scene = *tr.scene;
+    V3 accumulated{0, 0, 0};
+    V3 path_weight{1, 1, 1};
+    V3 p0 = r.at(1e5f);
+    V4 position{p0.x, p0.y, p0.z, 1e5f};
+    uint8_t first_id = 255;
+    bool last_delta = false;
+    std::vector<int> volume_stack; // material indices, insertion ordered (deviation B-13)
+
+    for (uint32_t b = 0;; ++b)
+    {
+        if (b > 3)                                                                // integrator.rs:166-177
+        {
+            float survive_prob = rs_min(max_element(path_weight), 0.9999f);
+            if (rng.next_f32() > survive_prob) break;
+            path_weight = path_weight / survive_prob;
+        }
+        HitInfo hi;
+        uint32_t blas_id, prim_id, inst_id;
+        if (tr.world_intersect(r, INF, &hi, &blas_id, &prim_id, &inst_id))       // integrator.rs:179
+        {
+            const int mat_index = scene.world.blas[blas_id].material;
+            const Material& material = scene.materials[mat_index];
+            if (b == 0)
+            {
+                V3 p = r.at(hi.t);
+                position = V4{p.x, p.y, p.z, hi.t};
+                first_id = (uint8_t)blas_id;
+            }
+            V3 wi = -r.d;
+
+            // participating media, integrator.rs:189-205
+            bool scattered = false;
+            float best_t = 0;
+            V3 best_dir{0, 0, 0};
+            for (int vm : volume_stack)
+            {
+                const Volume& v = scene.materials[vm].volume;
+                if (!v.has_scatter) continue;
+                float t;
+                V3 dir;
+                if (v.scatter(rng, r.d, hi.t, &t, &dir))
+                {
+                    if (!scattered || total_key(t) < total_key(best_t)) { best_t = t; best_dir = dir; }
+                    scattered = true;
+                }
+            }
+            {
+                float dist = scattered ? best_t : hi.t;
+                V3 w{1, 1, 1};
+                for (int vm : volume_stack)
+                {
+                    const Volume& v = scene.materials[vm].volume;
+                    if (v.has_absorption) w = w * v.get_transmission(dist);
+                }
+                path_weight = path_weight * w;
+            }
+            if (scattered)
+            {
+                last_delta = true;
+                r = Ray::make(r.at(best_t), best_dir);
+                if (b == max_bounces) break;
+                continue;
+            }
+
+            if (material.is_emissive())                                           // integrator.rs:207-214
+            {
+                if (!enable_nee || last_delta || b == 0) accumulated = vfma(material.get_emitted(), path_weight, accumulated);
+                break;
+            }
+            if (const Volume* v = material.get_volume())                           // integrator.rs:217-227
+            {
+                (void)v;
+                auto it = std::find(volume_stack.begin(), volume_stack.end(), mat_index);
+                if (hi.front_facing) { if (it == volume_stack.end()) volume_stack.push_back(mat_index); }
+                else if (it != volume_stack.end()) volume_stack.erase(it);
+            }
+            bool is_delta = material.is_delta();
+            if (enable_nee && !is_delta)                                           // integrator.rs:231-234
+            {
+                V3 e = estimate_direct_explicit(tr, rng, r, hi, material);
+                V3 s = estimate_direct_bsdf(tr, rng, r, hi, material);
+                accumulated = accumulated + path_weight * (e + s);
+            }
+            r = Ray::make(r.at(hi.t), material.scatter_direction(rng, r.d, hi.normal, hi.front_facing)); // integrator.rs:236-239
+            BsdfPdf info = material.get_bsdf_pdf(wi, r.d, hi);
+            if (info.pdf < MIN_PDF) break;                                         // integrator.rs:243-247
+            path_weight = path_weight * (material.get_weakening(r.d, hi.normal) * info.bsdf / info.pdf); // integrator.rs:249
+            last_delta = is_delta;
+        }
+        else
+        {
+            accumulated = accumulated + V3{0.006f, 0.006f, 0.006f} * path_weight;  // integrator.rs:263-266
+            break;
+        }
+        if (b == max_bounces) break;                                               // `for b in 0..=max_bounces`
+    }
+    Sample s;
+    s.position = position;
+    s.id = first_id;
+    if (is_finite(accumulated))                                                    // integrator.rs:272-280
+    {
+        V3 c = clamp_length_max(accumulated, 100.0f);
+        s.colour = V4{c.x, c.y, c.z, 1.0f};
+    }
+    else { s.colour = V4{0, 0, 0, 1.0f}; }
+    return s;
+}
+
+// main.rs:186-207 pixel closure (seed draw, Sobol jitter, u/v, camera ray)
+Ray primary_ray(const Camera& cam, const pto_render_cfg& cfg, uint32_t pixel, uint32_t sample, Rng* rng_out)
+{
+    uint32_t x = pixel % cfg.width, y = pixel / cfg.width;
+    Rng rng{stream_state0(cfg.seed, pixel, sample), 0};
+    uint32_t seed = rng.next_u32();                                                // main.rs:193
+    float off[2];
+    ss_sobol(cfg.n_sobol, sample, seed, off);                                      // main.rs:194 (index: deviation B-1)
+    float ox = off[0] - 0.5f, oy = off[1] - 0.5f;
+    float u = ((float)x + ox) / (float)cfg.width;                                  // main.rs:196
+    float v = ((float)y + oy) / (float)cfg.height;                                 // main.rs:197
+    *rng_out = rng;
+    return cam.create_ray(u, v);
+}
+
+} // namespace
+
+// ====================================================================== C API
+extern "C" {
+
+pto_ctx* pto_create(void) { return new pto_ctx(); }
+void pto_destroy(pto_ctx* c) { delete c; }
+
+int pto_add_material(pto_ctx* c, int kind, const float colour[3], float roughness, float ior, const pto_volume_desc* vol)
+{
+    Material m;
+    m.kind = kind;
+    m.colour = V3{colour[0], colour[1], colour[2]};
+    m.ior = ior;
+    if (kind == PTO_GGX_METAL || kind == PTO_GGX_DIELECTRIC) m.a = rs_clamp(powi2(roughness), 0.0001f, 0.9999f);
+    if (vol && vol->present)
+    {
+        m.has_volume = true;
+        if (vol->k != 0.0f) { m.volume.has_absorption = true; m.volume.absorption = V3{vol->absorption[0], vol->absorption[1], vol->absorption[2]} * vol->k; }
+        if (vol->c != 0.0f) { m.volume.has_scatter = true; m.volume.c = vol->c; m.volume.g = rs_clamp(vol->g, -0.999f, 0.999f); }
+    }
+    c->materials.push_back(m);
+    return (int)c->materials.size() - 1;
+}
+
+int pto_add_model(pto_ctx* c, const float* positions, const float* normals, uint32_t n_tris, int material, const float* affines,
+                  uint32_t n_inst)
+{
+    if (material < 0 || material >= (int)c->materials.size() || n_tris == 0) return -1;
+    ModelDesc m;
+    m.positions.assign(positions, positions + (size_t)n_tris * 9);
+    m.normals.assign(normals, normals + (size_t)n_tris * 9);
+    m.n_tris = n_tris;
+    m.material = material;
+    for (uint32_t i = 0; i < n_inst; ++i)
+    {
+        const float* a = affines + i * 12;
+        Affine f;
+        f.m.c0 = V3{a[0], a[4], a[8]};
+        f.m.c1 = V3{a[1], a[5], a[9]};
+        f.m.c2 = V3{a[2], a[6], a[10]};
+        f.t = V3{a[3], a[7], a[11]};
+        // model.rs:40-44: to_scale_rotation_translation().0 must equal (1,1,1) exactly
+        float det = dot(f.m.c2, cross(f.m.c0, f.m.c1));
+        V3 scale{length(f.m.c0) * rs_signum(det), length(f.m.c1), length(f.m.c2)};
+        if (!(scale.x == 1.0f && scale.y == 1.0f && scale.z == 1.0f)) return -4;
+        m.matrices.push_back(f);
+    }
+    c->models.push_back(std::move(m));
+    return (int)c->models.size() - 1;
+}
+
+int pto_build(pto_ctx* c)                                                          // scene.rs:21-35
+{
+    auto sc = std::make_unique<Scene>();
+    sc->materials = c->materials;
+    std::vector<const ModelDesc*> all, lights;
+    for (auto& m : c->models)
+    {
+        all.push_back(&m);
+        if (c->materials[m.material].is_emissive()) lights.push_back(&m);
+    }
+    if (all.empty()) return -1;
+    sc->world.build(all);
+    sc->lights.build(lights);
+    sc->has_lights = !lights.empty();
+    if (sc->has_lights) sc->light_sampler.build(sc->lights, sc->materials);
+    c->scene = std::move(sc);
+    return 0;
+}
+
+int pto_set_camera(pto_ctx* c, const float eye[3], const float target[3], float fov_y_deg, float aspect)
+{
+    c->camera.init(V3{eye[0], eye[1], eye[2]}, V3{target[0], target[1], target[2]}, fov_y_deg, aspect);
+    return 0;
+}
+
+int pto_camera_matrices(pto_ctx* c, float m34[12], float ip[16], float rm[16])
+{
+    if (!c->camera.set) return -1;
+    const Affine& a = c->camera.matrix;
+    float rows[12] = {a.m.c0.x, a.m.c1.x, a.m.c2.x, a.t.x, a.m.c0.y, a.m.c1.y, a.m.c2.y, a.t.y, a.m.c0.z, a.m.c1.z, a.m.c2.z, a.t.z};
+    std::memcpy(m34, rows, sizeof(rows));
+    std::memcpy(ip, &c->camera.inv_projection, 64); // column-major
+    std::memcpy(rm, &c->camera.ray_matrix, 64);
+    return 0;
+}
+
+int pto_create_ray(pto_ctx* c, float s, float t, float o[3], float d[3])
+{
+    if (!c->camera.set) return -1;
+    Ray r = c->camera.create_ray(s, t);
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+    d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+    return 0;
+}
+
+int pto_primary_ray(pto_ctx* c, const pto_render_cfg* cfg, uint32_t pixel, uint32_t sample, float o[3], float d[3])
+{
+    if (!c->camera.set) return -1;
+    Rng rng;
+    Ray r = primary_ray(c->camera, *cfg, pixel, sample, &rng);
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+    d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+    return 0;
+}
+
+static int render_impl(pto_ctx* c, const pto_render_cfg* cfg, float* accum, float* position, uint32_t* id, uint64_t* counters,
+                       float* samples_out)
+{
+    if (!c->scene || !c->camera.set) return -3;
+    if (cfg->enable_nee && !c->scene->has_lights) return -3;
+    const uint32_t W = cfg->width, H = cfg->height;
+    uint32_t r0 = cfg->row_begin, r1 = cfg->row_end;
+    if (r0 == 0 && r1 == 0) r1 = H;
+    unsigned nt = cfg->threads ? cfg->threads : std::max(1u, std::thread::hardware_concurrency() - 1); // main.rs:72
+    std::atomic<uint32_t> next_row{r0};
+    std::vector<Counters> ctrs(nt);
+    auto worker = [&](unsigned tid) {
+        Tracer tr(c->scene.get());
+        for (;;)
+        {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= r1) break;
+            for (uint32_t x = 0; x < W; ++x)
+            {
+                uint32_t pixel = y * W + x;
+                // accumulate.wgsl:20-23: acc += (rgb, 1), one sample after the other
+                V4 acc{0, 0, 0, 0};
+                if (accum) acc = V4{accum[pixel * 4 + 0], accum[pixel * 4 + 1], accum[pixel * 4 + 2], accum[pixel * 4 + 3]};
+                uint32_t idv = id ? id[pixel] : 0;
+                for (uint32_t s = 0; s < cfg->n_samples; ++s)
+                {
+                    uint32_t sample = cfg->first_sample + s;
+                    Rng rng;
+                    Ray ray = primary_ray(c->camera, *cfg, pixel, sample, &rng);
+                    Sample sm = integrate(tr, ray, rng, cfg->max_bounces, cfg->enable_nee != 0);
+                    tr.ctr.c[5]++;
+                    acc = V4{acc.x + sm.colour.x, acc.y + sm.colour.y, acc.z + sm.colour.z, acc.w + 1.0f};
+                    idv = (idv << 16) | (uint32_t)sm.id;                           // main.rs:206
+                    if (position && s + 1 == cfg->n_samples) std::memcpy(position + pixel * 4, &sm.position, 16);
+                    if (samples_out) std::memcpy(samples_out + ((size_t)s * W * H + pixel) * 4, &sm.colour, 16);
+                }
+                if (accum) std::memcpy(accum + pixel * 4, &acc, 16);
+                if (id) id[pixel] = idv;
+            }
+        }
+        ctrs[tid] = tr.ctr;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (counters)
+        for (int k = 0; k < PTO_N_COUNTERS; ++k)
+        {
+            counters[k] = 0;
+            for (auto& ct : ctrs) counters[k] += ct.c[k];
+        }
+    return 0;
+}
+
+int pto_render(pto_ctx* c, const pto_render_cfg* cfg, float* accum, float* position, uint32_t* id, uint64_t* counters)
+{
+    return render_impl(c, cfg, accum, position, id, counters, nullptr);
+}
+int pto_render_samples(pto_ctx* c, const pto_render_cfg* cfg, float* samples)
+{
+    return render_impl(c, cfg, nullptr, nullptr, nullptr, nullptr, samples);
+}
+
+int pto_integrate(pto_ctx* c, const pto_render_cfg* cfg, const float o[3], const float d[3], uint32_t pixel, uint32_t sample,
+                  uint32_t draws_consumed, float colour[4], float position[4], uint8_t* id)
+{
+    if (!c->scene) return -3;
+    Tracer tr(c->scene.get());
+    Rng rng{stream_state0(cfg->seed, pixel, sample), draws_consumed};
+    Ray r = Ray::make(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]});
+    Sample s = integrate(tr, r, rng, cfg->max_bounces, cfg->enable_nee != 0);
+    std::memcpy(colour, &s.colour, 16);
+    std::memcpy(position, &s.position, 16);
+    *id = s.id;
+    return 0;
+}
+
+int pto_trace_closest(pto_ctx* c, int which, uint32_t n, const float* o, const float* d, const float* tmax, float* t, float* u, float* v,
+                      uint32_t* inst, uint32_t* prim, float* normal, uint8_t* front)
+{
+    if (!c->scene) return -3;
+    Tracer tr(c->scene.get());
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        Ray r = Ray::make(V3{o[i * 3], o[i * 3 + 1], o[i * 3 + 2]}, V3{d[i * 3], d[i * 3 + 1], d[i * 3 + 2]});
+        HitInfo hi;
+        uint32_t b, p, in;
+        if (tl.intersect(tr.sc, r, tmax[i], &hi, &b, &p, &in))
+        {
+            t[i] = hi.t; u[i] = hi.u; v[i] = hi.v; inst[i] = in; prim[i] = p;
+            if (normal) { normal[i * 3] = hi.normal.x; normal[i * 3 + 1] = hi.normal.y; normal[i * 3 + 2] = hi.normal.z; }
+            if (front) front[i] = hi.front_facing;
+        }
+        else
+        {
+            t[i] = INF; u[i] = 0; v[i] = 0; inst[i] = 0xffffffffu; prim[i] = 0xffffffffu;
+            if (normal) { normal[i * 3] = normal[i * 3 + 1] = normal[i * 3 + 2] = 0; }
+            if (front) front[i] = 0;
+        }
+    }
+    return 0;
+}
+
+int pto_trace_any(pto_ctx* c, int which, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* hit)
+{
+    if (!c->scene) return -3;
+    Tracer tr(c->scene.get());
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        Ray r = Ray::make(V3{o[i * 3], o[i * 3 + 1], o[i * 3 + 2]}, V3{d[i * 3], d[i * 3 + 1], d[i * 3 + 2]});
+        hit[i] = tl.any_intersect(tr.sc, r, tmax[i]) ? 1 : 0;
+    }
+    return 0;
+}
+
+int pto_blas_count(pto_ctx* c) { return c->scene ? (int)c->scene->world.blas.size() : -3; }
+
+int pto_blas_dump(pto_ctx* c, int which, int blas, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a,
+                  uint32_t* b, uint32_t* n_prim_ids, uint32_t* prim_ids, uint32_t cap_nodes, uint32_t cap_ids)
+{
+    if (!c->scene) return -3;
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    if (blas < 0 || blas >= (int)tl.blas.size()) return -1;
+    const BLAS& bl = tl.blas[blas];
+    *n_nodes = (uint32_t)bl.nodes.size();
+    *root = bl.root;
+    uint32_t ids = 0;
+    for (size_t i = 0; i < bl.nodes.size(); ++i)
+    {
+        const BLASNode& n = bl.nodes[i];
+        uint32_t cnt = n.type == NODE_BRANCH ? 0 : (n.type == NODE_LEAF_SINGLE ? 1 : (uint32_t)n.prims.size());
+        if (i < cap_nodes)
+        {
+            std::memcpy(boxes6 + i * 6, &n.box, 24);
+            kind[i] = n.type == NODE_BRANCH ? 0 : 1;
+            a[i] = n.type == NODE_BRANCH ? n.left : ids;
+            b[i] = n.type == NODE_BRANCH ? n.right : cnt;
+        }
+        for (uint32_t k = 0; k < cnt; ++k)
+        {
+            if (ids < cap_ids) prim_ids[ids] = n.type == NODE_LEAF_SINGLE ? n.prim : n.prims[k];
+            ids++;
+        }
+    }
+    *n_prim_ids = ids;
+    return (bl.nodes.size() <= cap_nodes && ids <= cap_ids) ? 0 : -1;
+}
+
+int pto_tlas_dump(pto_ctx* c, int which, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
+                  uint32_t cap_nodes)
+{
+    if (!c->scene) return -3;
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    *n_nodes = (uint32_t)tl.nodes.size();
+    *root = tl.root;
+    for (size_t i = 0; i < tl.nodes.size() && i < cap_nodes; ++i)
+    {
+        const TLASNode& n = tl.nodes[i];
+        std::memcpy(boxes6 + i * 6, &n.box, 24);
+        kind[i] = n.leaf ? 1 : 0;
+        a[i] = n.leaf ? n.instance : n.left;
+        b[i] = n.leaf ? n.blas : n.right;
+    }
+    return tl.nodes.size() <= cap_nodes ? 0 : -1;
+}
+
+int pto_light_cdf(pto_ctx* c, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap)
+{
+    if (!c->scene) return -3;
+    const LightSampler& ls = c->scene->light_sampler;
+    *n = (uint32_t)ls.lights.size();
+    *max_weight = ls.max;
+    for (size_t i = 0; i < ls.lights.size() && i < cap; ++i)
+    {
+        pdf[i] = ls.lights[i].pdf; cdf[i] = ls.cdf[i]; blas[i] = ls.lights[i].blas; prim[i] = ls.lights[i].prim;
+    }
+    return ls.lights.size() <= cap ? 0 : -1;
+}
+
+int pto_triangle_dump(pto_ctx* c, int which, int blas, uint32_t prim, float out36[36])
+{
+    if (!c->scene) return -3;
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    if (blas < 0 || blas >= (int)tl.blas.size() || prim >= tl.blas[blas].primitives.size()) return -1;
+    const Triangle& t = tl.blas[blas].primitives[prim];
+    std::memcpy(out36, &t.n0, 16);
+    std::memcpy(out36 + 4, &t.n1, 16);
+    std::memcpy(out36 + 8, &t.n2, 16);
+    std::memcpy(out36 + 12, &t.positions, 36);
+    std::memcpy(out36 + 21, &t.normals, 36);
+    for (int i = 30; i < 36; ++i) out36[i] = 0;
+    return 0;
+}
+
+void pto_ss_sobol_raw(uint32_t n_points, uint32_t index, uint32_t seed, uint32_t out[3]) { ss_sobol_raw(n_points, index, seed, out); }
+void pto_ss_sobol(uint32_t n_points, uint32_t index, uint32_t seed, float out[2]) { ss_sobol(n_points, index, seed, out); }
+uint32_t pto_sobol_dim1(uint32_t index) { return sobol_dim1(index); }
+uint32_t pto_low_bias_hash(uint32_t x) { return low_bias_hash(x); }
+uint32_t pto_lk_hash(uint32_t x, uint32_t seed) { return lk_hash(x, seed); }
+uint64_t pto_wyrand(uint64_t seed, uint32_t k) { return wy_mix(seed + (uint64_t)(k + 1) * WY_INC); }
+uint64_t pto_stream_state0(uint64_t seed, uint32_t pixel, uint32_t sample) { return stream_state0(seed, pixel, sample); }
+
+// fn: 0 sin/cos(a) -> out0,out1 ; 1 exp(a) ; 2 ln(a) ; 3 hypot(a,b) ; 4 a/b ; 5 sqrt(a) ; 6 tan(a)
+void pto_math_batch(int fn, uint32_t n, const float* a, const float* b, float* out0, float* out1)
+{
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        switch (fn)
+        {
+        case 0: det_sincos(a[i], &out0[i], &out1[i]); break;
+        case 1: out0[i] = det_exp(a[i]); break;
+        case 2: out0[i] = det_ln(a[i]); break;
+        case 3: out0[i] = det_hypot(a[i], b[i]); break;
+        case 4: out0[i] = a[i] / b[i]; break;
+        case 5: out0[i] = std::sqrt(a[i]); break;
+        case 6: out0[i] = det_tan(a[i]); break;
+        }
+    }
+}
+
+int pto_material_eval(pto_ctx* c, int material, const float incoming[3], const float normal[3], int front_facing, uint64_t seed,
+                      uint32_t pixel, uint32_t sample, uint32_t draws_consumed, float out[9])
+{
+    if (material < 0 || material >= (int)c->materials.size()) return -1;
+    const Material& m = c->materials[material];
+    Rng rng{stream_state0(seed, pixel, sample), draws_consumed};
+    V3 in{incoming[0], incoming[1], incoming[2]}, n{normal[0], normal[1], normal[2]};
+    V3 wo = m.scatter_direction(rng, in, n, front_facing != 0);
+    HitInfo hi{n, 0, 0, 0, front_facing != 0};
+    BsdfPdf bp = m.get_bsdf_pdf(-in, wo, hi);
+    out[0] = wo.x; out[1] = wo.y; out[2] = wo.z;
+    out[3] = bp.bsdf.x; out[4] = bp.bsdf.y; out[5] = bp.bsdf.z;
+    out[6] = bp.pdf;
+    out[7] = m.get_weakening(wo, n);
+    out[8] = (float)(rng.k - draws_consumed);
+    return 0;
+}
+
+} // extern "C"

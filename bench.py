@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mray/s of the wavefront integrator on the Cornell-class scene at 1920x1080, 256 spp, depth 8
+(BASELINE.json configs[1]).  One "step" = one complete 256-spp render of the frame with the scene already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: rows are dealt to ranks in strips (no
+data-path collective while rendering) and each step ends with one RCCL gather of the framebuffer to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 256, 8
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_CLOSEST_RAY = 48      # 32 B ray in + 16 B hit out (BVH is LDS-resident on this scene)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this host's cores on a bounded
+    sample of the same workload: full 1920x1080 frame, as many spp as fit the budget (>= 1)."""
+    from oracle import oracle as O
+    from path_tracer_amd import scenes
+    o = O.Oracle(scenes.cornell_box(WIDTH, HEIGHT))
+    threads = max(1, (os.cpu_count() or 2) - 1)          # num_cpus::get() - 1, src/main.rs:72
+    t0 = time.perf_counter()
+    _, _, _, ctr = o.render(WIDTH, HEIGHT, 1, max_bounces=DEPTH, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = int(ctr[0] + ctr[1] + ctr[2])
+    spp = 1
+    extra = int(min(16, max(0, (seconds_budget - dt) // max(dt, 1e-3))))
+    if extra >= 1:
+        t0 = time.perf_counter()
+        _, _, _, ctr = o.render(WIDTH, HEIGHT, extra, first_sample=1, max_bounces=DEPTH, threads=threads)
+        dt = time.perf_counter() - t0
+        rays = int(ctr[0] + ctr[1] + ctr[2])
+        spp = extra
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": f"Cornell {WIDTH}x{HEIGHT}, {spp} spp of 256, depth {DEPTH}, {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--batch-spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from path_tracer_amd import api, scenes
+    from path_tracer_amd import dist as ptdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    strip = 4
+    r = api.Renderer(scenes.cornell_box(WIDTH, HEIGHT), WIDTH, HEIGHT, max_bounces=DEPTH, rank=rank, world_size=world, strip_rows=strip,
+                     batch_spp=args.batch_spp, device=dev.index, flags=api.FLAG_TIMING)
+    stream = torch.cuda.current_stream(dev)
+    r.set_stream(stream.cuda_stream)
+    n_rows = len(r.local_rows())
+
+    def step():
+        r.reset_accumulation()
+        r.render_device(0, args.spp)
+        if world > 1:
+            ptr, _ = r.accum_device_ptr()
+            fb = ptdist.wrap_device_framebuffer(ptr, n_rows, WIDTH, dev)
+            ptdist.gather_framebuffer(fb, HEIGHT, WIDTH, rank, world, strip, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    r.reset_stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    st = r.stats()
+    vals = torch.tensor([dt, float(st.rays), float(st.paths)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = vals[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = vals[1:].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dt, rays, paths = float(tmax[0]), float(sums[0]), float(sums[1])
+    else:
+        rays, paths = float(st.rays), float(st.paths)
+
+    if rank == 0:
+        launches = max(1, st.launches_trace_closest)
+        avg_ms = st.ms_trace_closest / launches
+        bytes_per_launch = BYTES_PER_CLOSEST_RAY * st.rays_closest / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mray/s at 1920x1080, 256 spp; achieved HBM GB/s in traversal kernel",
+            "value": rays / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box (36 triangles, 6 BLAS) {WIDTH}x{HEIGHT}, {args.spp} spp, depth {DEPTH}, NEE+MIS",
+                       "parallelism": f"rows/{world}", "mpaths_per_s": paths / dt / 1e6, "rays_per_path": rays / max(paths, 1.0)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_closest<LDS,WORLD>", "avg_launch_ms": avg_ms, "launches": int(launches),
+                         "algorithmic_bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": st.rays_closest / launches,
+                         "closest_Mray_per_s_in_kernel": st.rays_closest / max(st.ms_trace_closest, 1e-9) / 1e3},
+            "kernel_ms": {"trace_closest": st.ms_trace_closest, "trace_any": st.ms_trace_any, "trace_light": st.ms_trace_light,
+                          "shade": st.ms_shade, "generate": st.ms_generate, "accumulate": st.ms_accumulate},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/* libptmi — MI355X-native wavefront path-tracing core: C-ABI drop-in boundary.
+ *
+ * The reference (CouncilmanJeremyJamm/path_tracer, Rust) has no FFI today; its per-pixel integration loop is called
+ * in-crate from the rayon closure at src/main.rs:181-207.  This header is the seam a maintainer would bind with an
+ * `extern "C"` block + build.rs: plain pointers and sizes, int status codes, no C++ / torch types,
+ * nothing thrown across the boundary.  Each entry point cites the reference interface it replaces
+ * (paths relative to /root/reference).
+ *
+ * Threading: one thread at a time per pt_ctx.  All device memory is owned by the ctx; caller buffers are caller-owned.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+enum pt_status
+{
+    PT_OK = 0,
+    PT_ERR_ARG = -1,      /* bad argument / capacity */
+    PT_ERR_HIP = -2,      /* HIP runtime failure (no device, OOM, launch failure) */
+    PT_ERR_STATE = -3,    /* call order (render before build, no camera, NEE without lights ...) */
+    PT_ERR_NONRIGID = -4, /* model matrix carries scale: model.rs:40-44 asserts scale == (1,1,1) */
+    PT_ERR_LIMIT = -5     /* scene exceeds a packing limit of the device layout */
+};
+
+/* Material enum of material.rs:80-89; GGX splits into its two GGXModel variants (material.rs:176-184). */
+enum pt_material_kind
+{
+    PT_LAMBERTIAN = 0,     /* Lambertian::new(albedo)                           material.rs:99  */
+    PT_EMISSIVE = 1,       /* Emissive::new(emitted)                            material.rs:126 */
+    PT_SPECULAR = 2,       /* Specular::new(colour)                             material.rs:146 */
+    PT_GGX_METAL = 3,      /* GGX::new_metal(colour, roughness)                 material.rs:290 */
+    PT_GGX_DIELECTRIC = 4, /* GGX::new_dielectric(colour, roughness, ior, vol)  material.rs:305 */
+    PT_DIELECTRIC = 5      /* Dielectric::new(colour, ior, vol)                 material.rs:475 */
+};
+
+typedef struct pt_material_desc
+{
+    int32_t kind;             /* pt_material_kind */
+    float colour[3];          /* albedo / emitted / colour */
+    float roughness;          /* linear roughness (GGX): alpha = clamp(roughness^2, 1e-4, 0.9999) */
+    float ior;
+    int32_t has_volume;       /* Option<Volume>: Volume::new(absorption, k, c, g)  material/volume.rs:136 */
+    float vol_absorption[3];
+    float vol_k, vol_c, vol_g;
+} pt_material_desc;
+
+/* Compile-time constants of src/main.rs:43-51 and src/integrator.rs:10-11 made run-time. */
+typedef struct pt_config
+{
+    uint32_t width, height;   /* IMAGE_WIDTH / IMAGE_HEIGHT   main.rs:44-45 */
+    uint32_t max_bounces;     /* MAX_BOUNCES (inclusive)      main.rs:49, integrator.rs:163 */
+    uint32_t n_sobol;         /* NUM_POINTS of SobolSampler<N> main.rs:48 (0 => 512) */
+    uint32_t enable_nee;      /* ENABLE_NEE                   main.rs:51 */
+    uint64_t seed;            /* key of the counter-based per-(pixel,sample) WyRand streams */
+    /* multi-GPU row sharding (one process per GPU): rows are dealt to ranks in strips of `strip_rows` */
+    uint32_t rank, world_size, strip_rows;
+    /* wavefront batch: samples per pixel resident at once (0 => auto) */
+    uint32_t batch_spp;
+    int32_t device;           /* HIP device ordinal, -1 => current */
+    uint32_t flags;           /* PT_FLAG_* */
+} pt_config;
+
+enum
+{
+    PT_FLAG_TIMING = 1u,      /* bracket every kernel launch with HIP events (pt_get_stats kernel times) */
+    PT_FLAG_NO_LDS_SCENE = 2u /* force BVH reads from global memory even when the scene fits LDS */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+pt_ctx* pt_create(const pt_config* cfg);
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(pt_ctx* ctx);
+int pt_set_config(pt_ctx* ctx, const pt_config* cfg); /* change image size / bounces / seed / sharding between renders */
+
+/* ---- Scene::new(Vec<Model>)  src/scene.rs:21 ------------------------------------------------------------------ */
+/* returns the material index (>= 0) or a negative pt_status */
+int pt_add_material(pt_ctx* ctx, const pt_material_desc* desc);
+/* Model::new(path, material, matrices)  model.rs:36, with the OBJ file replaced by its triangle soup
+ * (positions / normals: n_tris * 3 vertices * xyz, the Vec<Vertex> load_obj returns, blas.rs:44-131);
+ * affine3x4_rowmajor: n_instances rigid transforms.  Returns the model (= BLAS) index or a negative pt_status. */
+int pt_add_model(pt_ctx* ctx, const float* positions_xyz, const float* normals_xyz, uint32_t n_tris, int material,
+                 const float* affine3x4_rowmajor, uint32_t n_instances);
+/* BLAS (SAH sweep, blas_bvh.rs:62-136) + world/light TLAS (agglomerative, tlas_bvh.rs:85-138) + LightSampler
+ * (light_sampler.rs:41-61) on the host; flattened for the device.  No GPU is touched until the first render/trace. */
+int pt_build(pt_ctx* ctx);
+
+/* ---- Camera::new / create_ray  src/camera.rs:17-31, 94-105 ---------------------------------------------------- */
+int pt_set_camera(pt_ctx* ctx, const float eye[3], const float target[3], float fov_y_deg, float aspect);
+int pt_camera_matrices(pt_ctx* ctx, float cam_to_world_3x4[12], float inv_proj_4x4_colmajor[16]);
+int pt_create_ray(pt_ctx* ctx, float s, float t, float o[3], float d[3]); /* host evaluation, for tests */
+
+/* ---- the per-frame pixel loop  src/main.rs:181-207 + accumulate.wgsl:20-23 ------------------------------------- */
+/* Renders samples [first_sample, first_sample+n_samples) of every local pixel on the GPU and adds them, in sample
+ * order, to the ctx-owned device accumulation buffer (sum rgb, n).  Outputs (any may be NULL) are host buffers of
+ * local_rows*width entries, row-major, row 0 = bottom (camera.rs:96):
+ *   data_rgba  : the accumulation buffer after this call (acc.rgb / acc.w is the displayed mean, shader.wgsl:63)
+ *   position   : first-hit xyz + t of the LAST sample (main.rs:205)
+ *   id         : (id << 16) | new_id applied once per sample (main.rs:206); in/out
+ * Blocking. */
+int pt_render(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples, float* data_rgba, float* position_xyzt, uint32_t* id);
+/* same, results stay on the device (no host copy); *_dev may be NULL or device pointers of the sizes above */
+int pt_render_device(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples);
+int pt_reset_accumulation(pt_ctx* ctx);
+/* device pointer of the accumulation buffer (float4 per local pixel) so that the caller (torch.distributed / RCCL
+ * gather) can read it without a host round trip; *n_pixels = local pixel count */
+int pt_accum_device_ptr(pt_ctx* ctx, void** dev_ptr, uint64_t* n_pixels);
+int pt_read_accumulation(pt_ctx* ctx, float* data_rgba);
+/* per-sample radiance (rgb,1) of the last pt_render* call's final batch is not kept; this renders n_samples and
+ * writes them un-accumulated: out[(s * local_pixels + pixel) * 4] (test hook for bit-exact comparison per sample) */
+int pt_render_samples(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples, float* samples_rgba);
+/* rows owned by this rank: local row ly <-> global row rows[ly] */
+int pt_local_rows(pt_ctx* ctx, uint32_t* n_rows, uint32_t* rows, uint32_t cap);
+/* HIP stream the library launches on (a hipStream_t); pass NULL to return to the library's own stream */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+int pt_synchronize(pt_ctx* ctx);
+
+/* ---- unit hooks: TLAS::intersect / any_intersect  src/tlas.rs:66, 111 ------------------------------------------ */
+/* which: 0 world TLAS, 1 lights TLAS.  Host SoA in, host SoA out.  miss => inst = prim = 0xffffffff, t = +inf.
+ * inst = TLAS leaf index in allocation order, prim = triangle index inside its BLAS (load order). */
+int pt_trace_closest(pt_ctx* ctx, int which, uint32_t n, const float* o_xyz, const float* d_xyz, const float* t_max, float* t,
+                     float* u, float* v, uint32_t* inst, uint32_t* prim);
+int pt_trace_any(pt_ctx* ctx, int which, uint32_t n, const float* o_xyz, const float* d_xyz, const float* t_max, uint8_t* hit);
+/* get_ss_sobol(index, seed)  src/sampling.rs:97 evaluated on the device */
+int pt_ss_sobol(pt_ctx* ctx, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy);
+/* device arithmetic probes: fn 0 sin/cos, 1 exp, 2 ln, 3 hypot(a,b), 4 a/b, 5 sqrt, 7 k-th f32 draw of stream (a=pixel bits,b=sample bits) */
+int pt_math_batch(pt_ctx* ctx, int fn, uint32_t n, const float* a, const float* b, float* out0, float* out1);
+/* MaterialTrait::scatter_direction + get_bsdf_pdf + get_weakening on the device for n (incoming, normal, front) tuples,
+ * drawing from stream (pixel[i], sample[i]) at draws_consumed; out[i*9..] = wo xyz, bsdf rgb, pdf, weakening, draws */
+int pt_material_eval(pt_ctx* ctx, int material, uint32_t n, const float* incoming_xyz, const float* normal_xyz, const uint8_t* front,
+                     const uint32_t* pixel, const uint32_t* sample, uint32_t draws_consumed, float* out9);
+
+/* ---- host-builder introspection (CPU only; compared against the oracle's builders) ----------------------------- */
+int pt_blas_count(pt_ctx* ctx);
+int pt_blas_dump(pt_ctx* ctx, int blas, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
+                 uint32_t* n_prim_ids, uint32_t* prim_ids, uint32_t cap_nodes, uint32_t cap_ids);
+int pt_tlas_dump(pt_ctx* ctx, int which, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
+                 uint32_t cap_nodes);
+int pt_light_cdf(pt_ctx* ctx, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap);
+int pt_triangle_dump(pt_ctx* ctx, int blas, uint32_t prim, float out36[36]);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+typedef struct pt_stats
+{
+    uint64_t rays_closest;       /* world.intersect call sites      integrator.rs:179 */
+    uint64_t rays_any;           /* world.any_intersect call sites  integrator.rs:56,103 */
+    uint64_t rays_light_closest; /* lights.intersect call sites     integrator.rs:100 */
+    uint64_t paths;
+    uint64_t launches_trace_closest; /* world closest-hit kernel launches in the timed region */
+    double ms_trace_closest;         /* their summed duration (HIP events on the launch stream; PT_FLAG_TIMING) */
+    double ms_trace_any, ms_trace_light, ms_shade, ms_generate, ms_accumulate;
+    double ms_total;                 /* wall of the render calls since the last reset, host clock around stream sync */
+    uint64_t scene_bytes;            /* nodes + triangles + instances resident for traversal */
+    uint32_t lds_scene;              /* 1 if traversal reads the BVH from LDS */
+    uint32_t stack_entries;
+    uint64_t state_bytes;            /* wavefront state + queues resident in HBM */
+} pt_stats;
+int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+int pt_reset_stats(pt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's Camera / Scene / integrate surface over the libptmi C-ABI (include/pt_api.h).
+
+    Scene::new(models)                 src/scene.rs:21        -> Renderer(scene_desc, ...)
+    Camera::new(...)                   src/camera.rs:17       -> Renderer.set_camera(CameraDesc)
+    per-frame pixel loop + accumulate  src/main.rs:181-207    -> Renderer.render(first_sample, n_samples)
+    TLAS::intersect / any_intersect    src/tlas.rs:66,111     -> Renderer.trace_closest / trace_any
+
+All compute happens in libptmi.so (HIP, gfx950).  If the library is missing or no GPU is present the calls raise:
+there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+from .scene_desc import CameraDesc, SceneDesc
+
+PT_OK = 0
+FLAG_TIMING = 1
+FLAG_NO_LDS_SCENE = 2
+DEFAULT_SEED = 0x5EED5EED
+
+# every symbol include/pt_api.h declares
+EXPORTS = [
+    "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_build", "pt_set_camera",
+    "pt_camera_matrices", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
+    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_trace_closest", "pt_trace_any",
+    "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
+    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats",
+]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("colour", C.c_float * 3), ("roughness", C.c_float), ("ior", C.c_float), ("has_volume", C.c_int32),
+                ("vol_absorption", C.c_float * 3), ("vol_k", C.c_float), ("vol_c", C.c_float), ("vol_g", C.c_float)]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_bounces", C.c_uint32), ("n_sobol", C.c_uint32),
+                ("enable_nee", C.c_uint32), ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32),
+                ("strip_rows", C.c_uint32), ("batch_spp", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("rays_light_closest", C.c_uint64), ("paths", C.c_uint64),
+                ("launches_trace_closest", C.c_uint64), ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double),
+                ("ms_trace_light", C.c_double), ("ms_shade", C.c_double), ("ms_generate", C.c_double), ("ms_accumulate", C.c_double),
+                ("ms_total", C.c_double), ("scene_bytes", C.c_uint64), ("lds_scene", C.c_uint32), ("stack_entries", C.c_uint32),
+                ("state_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+    @property
+    def rays(self):
+        return self.rays_closest + self.rays_any + self.rays_light_closest
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libptmi error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libptmi.so (building it in-tree if the sources are newer).  Raises if that is impossible."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if _build.is_stale():
+            path = _build.build()
+        L = C.CDLL(path)
+        vp, u32, f32p = C.c_void_p, C.c_uint32, C.c_void_p
+        L.pt_create.restype = vp
+        L.pt_create.argtypes = [C.POINTER(Config)]
+        L.pt_destroy.argtypes = [vp]
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_last_error.argtypes = [vp]
+        L.pt_set_config.argtypes = [vp, C.POINTER(Config)]
+        L.pt_add_material.argtypes = [vp, C.POINTER(MaterialDesc)]
+        L.pt_add_model.argtypes = [vp, f32p, f32p, u32, C.c_int, f32p, u32]
+        L.pt_build.argtypes = [vp]
+        L.pt_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.pt_camera_matrices.argtypes = [vp, vp, vp]
+        L.pt_create_ray.argtypes = [vp, C.c_float, C.c_float, vp, vp]
+        L.pt_render.argtypes = [vp, u32, u32, vp, vp, vp]
+        L.pt_render_device.argtypes = [vp, u32, u32]
+        L.pt_reset_accumulation.argtypes = [vp]
+        L.pt_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.pt_read_accumulation.argtypes = [vp, vp]
+        L.pt_render_samples.argtypes = [vp, u32, u32, vp]
+        L.pt_local_rows.argtypes = [vp, C.POINTER(u32), vp, u32]
+        L.pt_set_stream.argtypes = [vp, vp]
+        L.pt_synchronize.argtypes = [vp]
+        L.pt_trace_closest.argtypes = [vp, C.c_int, u32] + [vp] * 8
+        L.pt_trace_any.argtypes = [vp, C.c_int, u32] + [vp] * 4
+        L.pt_ss_sobol.argtypes = [vp, u32, u32, vp, vp, vp]
+        L.pt_math_batch.argtypes = [vp, C.c_int, u32, vp, vp, vp, vp]
+        L.pt_material_eval.argtypes = [vp, C.c_int, u32, vp, vp, vp, vp, vp, u32, vp]
+        L.pt_blas_count.argtypes = [vp]
+        L.pt_blas_dump.argtypes = [vp, C.c_int] + [vp] * 8 + [u32, u32]
+        L.pt_tlas_dump.argtypes = [vp, C.c_int] + [vp] * 6 + [u32]
+        L.pt_light_cdf.argtypes = [vp] + [vp] * 6 + [u32]
+        L.pt_triangle_dump.argtypes = [vp, C.c_int, u32, vp]
+        L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.pt_reset_stats.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Renderer:
+    """Scene + Camera + integrator behind one pt_ctx."""
+
+    def __init__(self, scene: SceneDesc, width: int, height: int, max_bounces: int = 8, n_sobol: int = 512, enable_nee: bool = True,
+                 seed: int = DEFAULT_SEED, rank: int = 0, world_size: int = 1, strip_rows: int = 4, batch_spp: int = 0, device: int = -1,
+                 flags: int = 0):
+        self.L = lib()
+        self.cfg = Config(width, height, max_bounces, n_sobol, int(enable_nee), seed, rank, world_size, strip_rows, batch_spp, device, flags)
+        self.ctx = C.c_void_p(self.L.pt_create(C.byref(self.cfg)))
+        if not self.ctx:
+            raise PtError(-1, "pt_create failed (bad configuration)")
+        self.desc = scene
+        mats = scene.materials()
+        for m in mats:
+            d = MaterialDesc()
+            d.kind = m.kind
+            d.colour[:] = m.colour
+            d.roughness, d.ior = m.roughness, m.ior
+            if m.volume is not None:
+                d.has_volume = 1
+                d.vol_absorption[:] = m.volume.absorption
+                d.vol_k, d.vol_c, d.vol_g = m.volume.k, m.volume.c, m.volume.g
+            self._chk(self.L.pt_add_material(self.ctx, C.byref(d)), allow_positive=True)
+        for mod in scene.models:
+            self._chk(self.L.pt_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0], mats.index(mod.material),
+                                          _p(mod.matrices), mod.matrices.shape[0]), allow_positive=True)
+        self._chk(self.L.pt_build(self.ctx))
+        if scene.camera is not None:
+            self.set_camera(scene.camera)
+
+    # ---- plumbing
+    def _chk(self, r, allow_positive=False):
+        if r < 0 or (r != 0 and not allow_positive):
+            raise PtError(r, self.L.pt_last_error(self.ctx).decode())
+        return r
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.pt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, **kw):
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        self._chk(self.L.pt_set_config(self.ctx, C.byref(self.cfg)))
+
+    def set_camera(self, cam: CameraDesc):
+        self._chk(self.L.pt_set_camera(self.ctx, _f3(cam.origin), _f3(cam.target), cam.fov, cam.aspect_ratio))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._chk(self.L.pt_set_stream(self.ctx, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._chk(self.L.pt_synchronize(self.ctx))
+
+    # ---- geometry of the local framebuffer
+    def local_rows(self) -> np.ndarray:
+        n = C.c_uint32()
+        self._chk(self.L.pt_local_rows(self.ctx, C.byref(n), None, 0))
+        rows = np.zeros(n.value, np.uint32)
+        self._chk(self.L.pt_local_rows(self.ctx, C.byref(n), _p(rows), n.value))
+        return rows
+
+    @property
+    def width(self):
+        return self.cfg.width
+
+    # ---- Camera
+    def camera_matrices(self):
+        m = np.zeros(12, np.float32)
+        ip = np.zeros(16, np.float32)
+        self._chk(self.L.pt_camera_matrices(self.ctx, _p(m), _p(ip)))
+        return m.reshape(3, 4), ip.reshape(4, 4).T.copy()
+
+    def create_ray(self, s, t):
+        o = np.zeros(3, np.float32)
+        d = np.zeros(3, np.float32)
+        self._chk(self.L.pt_create_ray(self.ctx, s, t, _p(o), _p(d)))
+        return o, d
+
+    # ---- integrate over the frame
+    def render(self, first_sample: int, n_samples: int, ident: Optional[np.ndarray] = None, want_position=True):
+        rows = len(self.local_rows())
+        acc = np.zeros((rows, self.cfg.width, 4), np.float32)
+        pos = np.zeros((rows, self.cfg.width, 4), np.float32) if want_position else None
+        idb = np.zeros((rows, self.cfg.width), np.uint32) if ident is None else ident
+        self._chk(self.L.pt_render(self.ctx, first_sample, n_samples, _p(acc), _p(pos), _p(idb)))
+        return acc, pos, idb
+
+    def render_device(self, first_sample: int, n_samples: int):
+        self._chk(self.L.pt_render_device(self.ctx, first_sample, n_samples))
+
+    def render_samples(self, first_sample: int, n_samples: int):
+        rows = len(self.local_rows())
+        out = np.zeros((n_samples, rows, self.cfg.width, 4), np.float32)
+        self._chk(self.L.pt_render_samples(self.ctx, first_sample, n_samples, _p(out)))
+        return out
+
+    def reset_accumulation(self):
+        self._chk(self.L.pt_reset_accumulation(self.ctx))
+
+    def read_accumulation(self):
+        rows = len(self.local_rows())
+        acc = np.zeros((rows, self.cfg.width, 4), np.float32)
+        self._chk(self.L.pt_read_accumulation(self.ctx, _p(acc)))
+        return acc
+
+    def accum_device_ptr(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(self.L.pt_accum_device_ptr(self.ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- unit hooks
+    def trace_closest(self, o, d, tmax=None, which=0):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        n = o.shape[0]
+        tm = None if tmax is None else np.ascontiguousarray(tmax, np.float32)
+        t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        inst = np.zeros(n, np.uint32); prim = np.zeros(n, np.uint32)
+        self._chk(self.L.pt_trace_closest(self.ctx, which, n, _p(o), _p(d), _p(tm), _p(t), _p(u), _p(v), _p(inst), _p(prim)))
+        return dict(t=t, u=u, v=v, inst=inst, prim=prim)
+
+    def trace_any(self, o, d, tmax, which=0):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        tm = np.ascontiguousarray(tmax, np.float32)
+        hit = np.zeros(o.shape[0], np.uint8)
+        self._chk(self.L.pt_trace_any(self.ctx, which, o.shape[0], _p(o), _p(d), _p(tm), _p(hit)))
+        return hit
+
+    def ss_sobol(self, n_points, index, seed):
+        index = np.ascontiguousarray(index, np.uint32)
+        seed = np.ascontiguousarray(seed, np.uint32)
+        out = np.zeros((index.size, 2), np.float32)
+        self._chk(self.L.pt_ss_sobol(self.ctx, n_points, index.size, _p(index), _p(seed), _p(out)))
+        return out
+
+    def math_batch(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        b = None if b is None else np.ascontiguousarray(b, np.float32)
+        o0 = np.zeros_like(a)
+        o1 = np.zeros_like(a)
+        self._chk(self.L.pt_math_batch(self.ctx, fn, a.size, _p(a), _p(b), _p(o0), _p(o1)))
+        return o0, o1
+
+    def material_eval(self, material, incoming, normal, front, pixel, sample, draws_consumed=0):
+        i = np.ascontiguousarray(incoming, np.float32); n = np.ascontiguousarray(normal, np.float32)
+        f = np.ascontiguousarray(front, np.uint8); px = np.ascontiguousarray(pixel, np.uint32); sm = np.ascontiguousarray(sample, np.uint32)
+        out = np.zeros((i.shape[0], 9), np.float32)
+        self._chk(self.L.pt_material_eval(self.ctx, material, i.shape[0], _p(i), _p(n), _p(f), _p(px), _p(sm), draws_consumed, _p(out)))
+        return out
+
+    # ---- host-builder introspection (CPU)
+    def blas_count(self):
+        return self._chk(self.L.pt_blas_count(self.ctx), allow_positive=True)
+
+    def blas_dump(self, blas, cap=1 << 20):
+        nn = C.c_uint32(); root = C.c_uint32(); nids = C.c_uint32()
+        boxes = np.zeros((cap, 6), np.float32); kind = np.zeros(cap, np.uint32); a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32)
+        ids = np.zeros(cap, np.uint32)
+        self._chk(self.L.pt_blas_dump(self.ctx, blas, C.byref(nn), C.byref(root), _p(boxes), _p(kind), _p(a), _p(b), C.byref(nids), _p(ids), cap, cap))
+        n = nn.value
+        return dict(root=root.value, boxes=boxes[:n].copy(), kind=kind[:n].copy(), a=a[:n].copy(), b=b[:n].copy(), prim_ids=ids[:nids.value].copy())
+
+    def tlas_dump(self, which=0, cap=1 << 16):
+        nn = C.c_uint32(); root = C.c_uint32()
+        boxes = np.zeros((cap, 6), np.float32); kind = np.zeros(cap, np.uint32); a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32)
+        self._chk(self.L.pt_tlas_dump(self.ctx, which, C.byref(nn), C.byref(root), _p(boxes), _p(kind), _p(a), _p(b), cap))
+        n = nn.value
+        return dict(root=root.value, boxes=boxes[:n].copy(), kind=kind[:n].copy(), a=a[:n].copy(), b=b[:n].copy())
+
+    def light_cdf(self, cap=1 << 20):
+        n = C.c_uint32(); mx = C.c_float()
+        pdf = np.zeros(cap, np.float32); cdf = np.zeros(cap, np.float32); bl = np.zeros(cap, np.uint32); pr = np.zeros(cap, np.uint32)
+        self._chk(self.L.pt_light_cdf(self.ctx, C.byref(n), _p(pdf), _p(cdf), _p(bl), _p(pr), C.byref(mx), cap))
+        k = n.value
+        return dict(pdf=pdf[:k].copy(), cdf=cdf[:k].copy(), blas=bl[:k].copy(), prim=pr[:k].copy(), max=mx.value)
+
+    def triangle(self, blas, prim):
+        out = np.zeros(36, np.float32)
+        self._chk(self.L.pt_triangle_dump(self.ctx, blas, prim, _p(out)))
+        return out
+
+    # ---- measurement
+    def stats(self) -> Stats:
+        s = Stats()
+        self._chk(self.L.pt_get_stats(self.ctx, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._chk(self.L.pt_reset_stats(self.ctx))

@@ -1,0 +1,914 @@
+// libptmi C-ABI (include/pt_api.h): context, device residency, the wavefront render loop and the unit hooks.
+// Host scene construction lives in pt_scene.cpp, kernels in pt_kernels.hip.  No CPU fallback exists: every compute
+// entry point needs a HIP device and reports PT_ERR_HIP without one.
+#include "../../include/pt_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt_kernels.h"
+#include "pt_scene.h"
+
+using namespace pt;
+
+namespace {
+
+enum TimeCat { T_GEN = 0, T_WORLD, T_ANY, T_LIGHT, T_SHADE, T_ACCUM, T_COUNT };
+
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct pt_ctx
+{
+    pt_config cfg{};
+    HostScene scene;
+    std::string err;
+    std::mutex mu;
+
+    bool dev_ready = false;
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // scene residency
+    bool scene_uploaded = false;
+    DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights;
+    SceneView sv{};
+    bool lds_scene = false;
+    uint32_t block_threads = 256, trace_blocks = 1024;
+    bool class_present[Q_COUNT] = {true, false, false, false, false};
+
+    // frame
+    std::vector<uint32_t> rows; // local row -> global row
+    uint32_t local_pixels = 0;
+    DevBuf d_accum, d_position, d_id;
+
+    // wavefront
+    size_t cap_paths = 0;
+    uint32_t cap_rows = 0;
+    std::vector<DevBuf> pool;
+    WavefrontBuffers wb{};
+    Counters* h_counters = nullptr; // pinned
+
+    // stats
+    pt_stats stats{};
+    struct Ev { hipEvent_t a, b; int cat; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const std::string& msg)
+{
+    c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) return fail((c), PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+void dev_free(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b = DevBuf();
+}
+int dev_alloc(pt_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p) return PT_OK;
+    dev_free(b);
+    bytes = std::max<size_t>(bytes, 16);
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return PT_OK;
+}
+
+void compute_rows(pt_ctx* c)
+{
+    const pt_config& g = c->cfg;
+    c->rows.clear();
+    const uint32_t world = std::max(1u, g.world_size), strip = std::max(1u, g.strip_rows);
+    for (uint32_t y = 0; y < g.height; ++y)
+        if ((y / strip) % world == g.rank) c->rows.push_back(y);
+    c->local_pixels = (uint32_t)c->rows.size() * g.width;
+}
+
+int normalise_config(pt_ctx* c, const pt_config* in)
+{
+    pt_config g = *in;
+    if (g.width == 0 || g.height == 0) return fail(c, PT_ERR_ARG, "width/height must be non-zero");
+    if (g.n_sobol == 0) g.n_sobol = 512;
+    if (g.world_size == 0) g.world_size = 1;
+    if (g.strip_rows == 0) g.strip_rows = 4;
+    if (g.rank >= g.world_size) return fail(c, PT_ERR_ARG, "rank >= world_size");
+    if ((uint64_t)g.width * g.height > 0x7fffffffull) return fail(c, PT_ERR_ARG, "image too large");
+    c->cfg = g;
+    compute_rows(c);
+    return PT_OK;
+}
+
+int ensure_device(pt_ctx* c)
+{
+    if (c->dev_ready) return PT_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(c, PT_ERR_HIP, "no HIP device available (libptmi has no CPU path)");
+    if (c->cfg.device >= 0) HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipGetDevice(&c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    if (!c->stream) c->stream = c->own_stream;
+    c->dev_ready = true;
+    return PT_OK;
+}
+
+int upload_scene(pt_ctx* c)
+{
+    if (c->scene_uploaded) return PT_OK;
+    if (!c->scene.built) return fail(c, PT_ERR_STATE, "pt_build has not been called");
+    int r = ensure_device(c);
+    if (r) return r;
+    const FlatScene& f = c->scene.flat;
+    const size_t nb = f.nodes.size() * sizeof(DNode), tb = f.tri_isect.size() * sizeof(DTriIsect), ib = f.instances.size() * sizeof(DInstance);
+    std::vector<uint8_t> blob(nb + tb + ib);
+    std::memcpy(blob.data(), f.nodes.data(), nb);
+    std::memcpy(blob.data() + nb, f.tri_isect.data(), tb);
+    std::memcpy(blob.data() + nb + tb, f.instances.data(), ib);
+    if ((r = dev_alloc(c, c->d_blob, blob.size()))) return r;
+    HIPCHK(c, hipMemcpy(c->d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        int rr = dev_alloc(c, b, bytes);
+        if (rr) return rr;
+        if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        return PT_OK;
+    };
+    if ((r = up(c->d_tri_shade, f.tri_shade.data(), f.tri_shade.size() * sizeof(DTriVerts)))) return r;
+    if ((r = up(c->d_tri_pos, f.tri_pos.data(), f.tri_pos.size() * sizeof(DTriVerts)))) return r;
+    if ((r = up(c->d_tri_orig, f.tri_orig.data(), f.tri_orig.size() * 4))) return r;
+    if ((r = up(c->d_materials, f.materials.data(), f.materials.size() * sizeof(DMaterial)))) return r;
+    if ((r = up(c->d_lights, f.lights.data(), f.lights.size() * sizeof(DLight)))) return r;
+
+    SceneView& sv = c->sv;
+    uint8_t* base = (uint8_t*)c->d_blob.p;
+    sv.nodes = (const DNode*)base;
+    sv.tri_isect = (const DTriIsect*)(base + nb);
+    sv.instances = (const DInstance*)(base + nb + tb);
+    sv.tri_shade = (const DTriVerts*)c->d_tri_shade.p;
+    sv.tri_pos = (const DTriVerts*)c->d_tri_pos.p;
+    sv.tri_orig = (const uint32_t*)c->d_tri_orig.p;
+    sv.materials = (const DMaterial*)c->d_materials.p;
+    sv.lights = (const DLight*)c->d_lights.p;
+    sv.n_nodes = (uint32_t)f.nodes.size();
+    sv.n_tris = (uint32_t)f.tri_isect.size();
+    sv.n_instances = (uint32_t)f.instances.size();
+    sv.n_materials = (uint32_t)f.materials.size();
+    sv.n_lights = (uint32_t)f.lights.size();
+    sv.world_root = f.world_root;
+    sv.lights_root = f.lights_root;
+    sv.prim_bits = f.prim_bits;
+    sv.light_weight_sum = f.light_weight_sum;
+    sv.blob_bytes = (uint32_t)blob.size();
+    sv.stack_entries = f.stack_entries;
+
+    // launch geometry of the traversal kernels: BVH in LDS when it is small, per-lane stacks always in LDS
+    c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
+    const size_t blob_lds = c->lds_scene ? blob.size() : 0;
+    uint32_t threads = 256;
+    while (threads > 64 && blob_lds + (size_t)sv.stack_entries * threads * 8 > 64 * 1024) threads >>= 1;
+    if (blob_lds + (size_t)sv.stack_entries * threads * 8 > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
+    c->block_threads = threads;
+    const size_t lds = blob_lds + (size_t)sv.stack_entries * threads * 8;
+    uint32_t per_cu = (uint32_t)std::min<size_t>((160 * 1024) / std::max<size_t>(lds, 1), 2048 / threads);
+    per_cu = std::max(1u, std::min(per_cu, 8u));
+    c->trace_blocks = (uint32_t)c->n_cus * per_cu;
+
+    for (uint32_t q = 0; q < Q_COUNT; ++q) c->class_present[q] = (q == Q_TERMINAL);
+    for (const DInstance& in : f.instances) c->class_present[in.qclass] = true;
+    c->scene_uploaded = true;
+    c->stats.scene_bytes = blob.size();
+    c->stats.lds_scene = c->lds_scene;
+    c->stats.stack_entries = sv.stack_entries;
+    return PT_OK;
+}
+
+TraceLaunch trace_launch(pt_ctx* c)
+{
+    TraceLaunch tl;
+    tl.scene = c->sv;
+    tl.blob = c->d_blob.p;
+    tl.lds_scene = c->lds_scene;
+    tl.grid_blocks = c->trace_blocks;
+    tl.block_threads = c->block_threads;
+    return tl;
+}
+
+int ensure_frame(pt_ctx* c)
+{
+    int r;
+    const size_t px = std::max<uint32_t>(c->local_pixels, 1);
+    const bool fresh = c->d_accum.bytes < px * 16;
+    if ((r = dev_alloc(c, c->d_accum, px * 16))) return r;
+    if ((r = dev_alloc(c, c->d_position, px * 16))) return r;
+    if ((r = dev_alloc(c, c->d_id, px * 4))) return r;
+    if (fresh)
+    {
+        HIPCHK(c, hipMemsetAsync(c->d_accum.p, 0, c->d_accum.bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_position.p, 0, c->d_position.bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_id.p, 0, c->d_id.bytes, c->stream));
+    }
+    return PT_OK;
+}
+
+int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
+{
+    if (c->cap_paths >= n_paths && c->cap_rows >= rows) return PT_OK;
+    for (DevBuf& b : c->pool) dev_free(b);
+    c->pool.clear();
+    if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
+    n_paths = std::max<size_t>(n_paths, 64);
+    size_t total = 0;
+    auto take = [&](size_t bytes, void** out) -> int {
+        DevBuf b;
+        int r = dev_alloc(c, b, bytes);
+        if (r) return r;
+        c->pool.push_back(b);
+        *out = b.p;
+        total += b.bytes;
+        return PT_OK;
+    };
+    int r;
+    WavefrontBuffers& w = c->wb;
+#define TAKE(ptr, bytes)                                  \
+    if ((r = take((bytes), (void**)&(ptr)))) return r;
+    TAKE(w.st.pw, n_paths * 16);
+    TAKE(w.st.acc, n_paths * 16);
+    TAKE(w.st.nee_e, n_paths * 16);
+    TAKE(w.st.nee_pw, n_paths * 16);
+    TAKE(w.st.nee_b, n_paths * 16);
+    TAKE(w.st.lhit, n_paths * 16);
+    TAKE(w.st.occl_e, n_paths * 4);
+    TAKE(w.st.occl_b, n_paths * 4);
+    TAKE(w.st.first_pos, n_paths * 16);
+    TAKE(w.st.first_id, n_paths * 4);
+    for (int k = 0; k < 2; ++k)
+    {
+        TAKE(w.rq[k].a, n_paths * 16);
+        TAKE(w.rq[k].b, n_paths * 16);
+        TAKE(w.rq_lchain[k].a, n_paths * 16);
+        TAKE(w.rq_lchain[k].b, n_paths * 16);
+        TAKE(w.q_term[k], n_paths * 4);
+    }
+    TAKE(w.rq_shadow.a, n_paths * 16);
+    TAKE(w.rq_shadow.b, n_paths * 16);
+    TAKE(w.hits, n_paths * 16);
+    w.q_shade[Q_TERMINAL] = nullptr;
+    for (uint32_t q = 1; q < Q_COUNT; ++q)
+    {
+        if (c->class_present[q]) { TAKE(w.q_shade[q], n_paths * 4); }
+        else w.q_shade[q] = nullptr;
+    }
+    TAKE(w.counters, (size_t)rows * sizeof(Counters));
+#undef TAKE
+    HIPCHK(c, hipHostMalloc((void**)&c->h_counters, (size_t)rows * sizeof(Counters), hipHostMallocDefault));
+    c->cap_paths = n_paths;
+    c->cap_rows = rows;
+    c->stats.state_bytes = total;
+    return PT_OK;
+}
+
+struct Timer
+{
+    pt_ctx* c;
+    int cat;
+    bool on;
+    size_t slot = 0;
+    Timer(pt_ctx* c_, int cat_) : c(c_), cat(cat_), on((c_->cfg.flags & PT_FLAG_TIMING) != 0)
+    {
+        if (!on) return;
+        if (c->ev_used == c->ev_pool.size())
+        {
+            pt_ctx::Ev e;
+            (void)hipEventCreate(&e.a);
+            (void)hipEventCreate(&e.b);
+            c->ev_pool.push_back(e);
+        }
+        slot = c->ev_used++;
+        c->ev_pool[slot].cat = cat;
+        (void)hipEventRecord(c->ev_pool[slot].a, c->stream);
+    }
+    ~Timer()
+    {
+        if (on) (void)hipEventRecord(c->ev_pool[slot].b, c->stream);
+    }
+};
+
+void harvest_events(pt_ctx* c)
+{
+    double ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < c->ev_used; ++i)
+    {
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) ms[c->ev_pool[i].cat] += t;
+        if (c->ev_pool[i].cat == T_WORLD) c->stats.launches_trace_closest++;
+    }
+    c->ev_used = 0;
+    c->stats.ms_generate += ms[T_GEN];
+    c->stats.ms_trace_closest += ms[T_WORLD];
+    c->stats.ms_trace_any += ms[T_ANY];
+    c->stats.ms_trace_light += ms[T_LIGHT];
+    c->stats.ms_shade += ms[T_SHADE];
+    c->stats.ms_accumulate += ms[T_ACCUM];
+}
+
+// one wavefront batch: samples [first, first+count) of every local pixel
+int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out)
+{
+    const pt_config& g = c->cfg;
+    RenderParams rp{};
+    rp.width = g.width;
+    rp.height = g.height;
+    rp.local_rows = (uint32_t)c->rows.size();
+    rp.local_pixels = c->local_pixels;
+    rp.rank = g.rank;
+    rp.world_size = g.world_size;
+    rp.strip_rows = g.strip_rows;
+    rp.first_sample = first_sample;
+    rp.batch_samples = count;
+    rp.n_paths = c->local_pixels * count;
+    rp.max_bounces = g.max_bounces;
+    rp.n_sobol = g.n_sobol;
+    rp.enable_nee = g.enable_nee;
+    rp.seed = g.seed;
+    const uint32_t rows = g.max_bounces + 2;
+    hipStream_t s = c->stream;
+    const WavefrontBuffers& wb = c->wb;
+    const TraceLaunch tl = trace_launch(c);
+    CameraView cam{};
+    std::memcpy(cam.ray_matrix, c->scene.camera.ray_matrix, 64);
+    cam.eye[0] = c->scene.camera.matrix.t.x;
+    cam.eye[1] = c->scene.camera.matrix.t.y;
+    cam.eye[2] = c->scene.camera.matrix.t.z;
+
+    HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
+    { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
+    const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * 8);
+    const bool nee = g.enable_nee != 0;
+    uint32_t last_row = rows - 1;
+    for (uint32_t b = 0; b <= g.max_bounces; ++b)
+    {
+        if (b > 0 && nee)
+        {
+            { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, b - 1); }
+            { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, b - 1); }
+            { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, b - 1); }
+        }
+        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b); }
+        for (uint32_t q = 0; q < Q_COUNT; ++q)
+            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks); }
+        // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
+        if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
+        {
+            HIPCHK(c, hipMemcpyAsync(c->h_counters + b + 1, wb.counters + b + 1, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            const Counters& nx = c->h_counters[b + 1];
+            if (nx.n_closest == 0) { last_row = b + 1; break; }
+        }
+    }
+    if (last_row == rows - 1) last_row = g.max_bounces + 1;
+    // the last shading pass may still owe direct-light estimates: trace them, then a resolve-only terminal pass
+    if (nee)
+    {
+        { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, last_row - 1); }
+        { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, last_row - 1); }
+        { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, last_row - 1); }
+        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks); }
+    }
+    if (samples_out) launch_store_samples(s, rp, wb, samples_out);
+    else
+    {
+        Timer t(c, T_ACCUM);
+        launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    for (uint32_t r = 0; r < rows; ++r)
+    {
+        const Counters& k = c->h_counters[r];
+        c->stats.rays_closest += k.n_closest;
+        c->stats.rays_any += (uint64_t)k.n_shadow + k.n_lchain_hit;
+        c->stats.rays_light_closest += k.n_lchain;
+    }
+    c->stats.paths += rp.n_paths;
+    harvest_events(c);
+    return PT_OK;
+}
+
+int precheck(pt_ctx* c)
+{
+    if (!c->scene.built) return fail(c, PT_ERR_STATE, "pt_build has not been called");
+    if (!c->scene.camera.set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
+    if (c->cfg.enable_nee && c->scene.flat.lights.empty()) return fail(c, PT_ERR_STATE, "NEE is enabled but the scene has no emissive model");
+    return PT_OK;
+}
+
+int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* samples_out)
+{
+    int r;
+    if ((r = precheck(c))) return r;
+    if (n_samples == 0 || c->local_pixels == 0) return PT_OK;
+    if ((r = upload_scene(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t max_paths = 24u << 20;
+    uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
+    batch = std::min(batch, n_samples);
+    if ((uint64_t)batch * c->local_pixels > 0x7fffffffull) return fail(c, PT_ERR_ARG, "batch too large");
+    const uint32_t n_batches = (n_samples + batch - 1) / batch;
+    batch = (n_samples + n_batches - 1) / n_batches;
+    if ((r = ensure_wavefront(c, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;
+    DevBuf d_samples;
+    if (samples_out && (r = dev_alloc(c, d_samples, (size_t)batch * c->local_pixels * 16))) return r;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t done = 0; done < n_samples; done += batch)
+    {
+        const uint32_t cnt = std::min(batch, n_samples - done);
+        r = run_batch(c, first_sample + done, cnt, done + cnt == n_samples, samples_out ? (f4*)d_samples.p : nullptr);
+        if (r) { dev_free(d_samples); return r; }
+        if (samples_out)
+        {
+            hipError_t e = hipMemcpy(samples_out + (size_t)done * c->local_pixels * 4, d_samples.p, (size_t)cnt * c->local_pixels * 16, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { dev_free(d_samples); return fail(c, PT_ERR_HIP, hipGetErrorString(e)); }
+        }
+    }
+    c->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    dev_free(d_samples);
+    return PT_OK;
+}
+
+} // namespace
+
+// ====================================================================================================== C-ABI
+extern "C" {
+
+pt_ctx* pt_create(const pt_config* cfg)
+{
+    if (!cfg) return nullptr;
+    pt_ctx* c = new (std::nothrow) pt_ctx();
+    if (!c) return nullptr;
+    if (normalise_config(c, cfg) != PT_OK)
+    {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void pt_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    if (c->dev_ready)
+    {
+        (void)hipStreamSynchronize(c->stream);
+        for (DevBuf& b : c->pool) dev_free(b);
+        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_accum, &c->d_position, &c->d_id};
+        for (DevBuf* b : bufs) dev_free(*b);
+        if (c->h_counters) (void)hipHostFree(c->h_counters);
+        for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
+    delete c;
+}
+
+const char* pt_last_error(pt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pt_set_config(pt_ctx* c, const pt_config* cfg)
+{
+    if (!c || !cfg) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const uint32_t old_px = c->local_pixels;
+    const int old_dev = c->cfg.device;
+    int r = normalise_config(c, cfg);
+    if (r) return r;
+    if (c->dev_ready && cfg->device != old_dev && cfg->device >= 0) return fail(c, PT_ERR_STATE, "device cannot change after first use");
+    if (c->local_pixels != old_px)
+    {
+        dev_free(c->d_accum);
+        dev_free(c->d_position);
+        dev_free(c->d_id);
+    }
+    return PT_OK;
+}
+
+int pt_add_material(pt_ctx* c, const pt_material_desc* d)
+{
+    if (!c || !d) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r = c->scene.add_material(d->kind, d->colour, d->roughness, d->ior, d->has_volume != 0, d->vol_absorption, d->vol_k, d->vol_c, d->vol_g);
+    if (r < 0) return fail(c, PT_ERR_ARG, "bad material description");
+    c->scene_uploaded = false;
+    return r;
+}
+
+int pt_add_model(pt_ctx* c, const float* positions, const float* normals, uint32_t n_tris, int material, const float* affines, uint32_t n_inst)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r = c->scene.add_model(positions, normals, n_tris, material, affines, n_inst);
+    if (r == -4) return fail(c, PT_ERR_NONRIGID, "Model matrix can only contain translation and rotation");
+    if (r < 0) return fail(c, PT_ERR_ARG, "bad model description");
+    c->scene_uploaded = false;
+    return r;
+}
+
+int pt_build(pt_ctx* c)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (const DMaterial& m : c->scene.materials)
+        if (m.has_volume) return fail(c, PT_ERR_LIMIT, "participating media (Option<Volume>) are not implemented in the GPU integrator yet");
+    std::string err;
+    int r = c->scene.build(&err);
+    c->scene_uploaded = false;
+    if (r) return fail(c, r == -5 ? PT_ERR_LIMIT : PT_ERR_STATE, err);
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx* c, const float eye[3], const float target[3], float fov_y_deg, float aspect)
+{
+    if (!c || !eye || !target) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->scene.set_camera(eye, target, fov_y_deg, aspect);
+    return PT_OK;
+}
+
+int pt_camera_matrices(pt_ctx* c, float m34[12], float inv_proj[16])
+{
+    if (!c || !c->scene.camera.set) return PT_ERR_STATE;
+    const xf34& a = c->scene.camera.matrix;
+    const float rows[12] = {a.m.c0.x, a.m.c1.x, a.m.c2.x, a.t.x, a.m.c0.y, a.m.c1.y, a.m.c2.y, a.t.y, a.m.c0.z, a.m.c1.z, a.m.c2.z, a.t.z};
+    if (m34) std::memcpy(m34, rows, sizeof(rows));
+    if (inv_proj) std::memcpy(inv_proj, c->scene.camera.inv_proj, 64);
+    return PT_OK;
+}
+
+int pt_create_ray(pt_ctx* c, float s, float t, float o[3], float d[3])
+{
+    if (!c || !c->scene.camera.set) return PT_ERR_STATE;
+    c->scene.create_ray(s, t, o, d);
+    return PT_OK;
+}
+
+int pt_render_device(pt_ctx* c, uint32_t first_sample, uint32_t n_samples)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return render_common(c, first_sample, n_samples, nullptr);
+}
+
+int pt_render(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* data, float* position, uint32_t* id)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = precheck(c))) return r;
+    if ((r = upload_scene(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t px = c->local_pixels;
+    if (id && px) HIPCHK(c, hipMemcpyAsync(c->d_id.p, id, px * 4, hipMemcpyHostToDevice, c->stream));
+    if ((r = render_common(c, first_sample, n_samples, nullptr))) return r;
+    if (data && px) HIPCHK(c, hipMemcpyAsync(data, c->d_accum.p, px * 16, hipMemcpyDeviceToHost, c->stream));
+    if (position && px) HIPCHK(c, hipMemcpyAsync(position, c->d_position.p, px * 16, hipMemcpyDeviceToHost, c->stream));
+    if (id && px) HIPCHK(c, hipMemcpyAsync(id, c->d_id.p, px * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_render_samples(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* samples)
+{
+    if (!c || !samples) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return render_common(c, first_sample, n_samples, samples);
+}
+
+int pt_reset_accumulation(pt_ctx* c)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    HIPCHK(c, hipMemsetAsync(c->d_accum.p, 0, c->d_accum.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_id.p, 0, c->d_id.bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_accum_device_ptr(pt_ctx* c, void** p, uint64_t* n)
+{
+    if (!c || !p) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    *p = c->d_accum.p;
+    if (n) *n = c->local_pixels;
+    return PT_OK;
+}
+
+int pt_read_accumulation(pt_ctx* c, float* data)
+{
+    if (!c || !data) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    HIPCHK(c, hipMemcpyAsync(data, c->d_accum.p, (size_t)c->local_pixels * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_local_rows(pt_ctx* c, uint32_t* n_rows, uint32_t* rows, uint32_t cap)
+{
+    if (!c || !n_rows) return PT_ERR_ARG;
+    *n_rows = (uint32_t)c->rows.size();
+    if (rows)
+        for (uint32_t i = 0; i < cap && i < c->rows.size(); ++i) rows[i] = c->rows[i];
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx* c, void* stream)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c)
+{
+    if (!c) return PT_ERR_ARG;
+    if (!c->dev_ready) return PT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// ---- unit hooks
+static int upload_rays(pt_ctx* c, uint32_t n, const float* o, const float* d, const float* tmax, DevBuf& da, DevBuf& db, DevBuf& dhead)
+{
+    std::vector<f4> a(n), b(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        a[i] = f4{o[3 * i], o[3 * i + 1], o[3 * i + 2], tmax ? tmax[i] : __builtin_inff()};
+        b[i] = f4{d[3 * i], d[3 * i + 1], d[3 * i + 2], from_bits(i)};
+    }
+    int r;
+    if ((r = dev_alloc(c, da, (size_t)n * 16)) || (r = dev_alloc(c, db, (size_t)n * 16)) || (r = dev_alloc(c, dhead, 16))) return r;
+    HIPCHK(c, hipMemcpyAsync(da.p, a.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db.p, b.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    const uint32_t head[4] = {0, n, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(dhead.p, head, 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_trace_closest(pt_ctx* c, int which, uint32_t n, const float* o, const float* d, const float* tmax, float* t, float* u, float* v,
+                     uint32_t* inst, uint32_t* prim)
+{
+    if (!c || !o || !d || !t || !u || !v || !inst || !prim) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = upload_scene(c))) return r;
+    if (n == 0) return PT_OK;
+    const uint32_t root = which ? c->sv.lights_root : c->sv.world_root;
+    if (root == MISS_ID)
+    {
+        for (uint32_t i = 0; i < n; ++i) { t[i] = __builtin_inff(); u[i] = v[i] = 0; inst[i] = prim[i] = MISS_ID; }
+        return PT_OK;
+    }
+    DevBuf da, db, dh, dhit;
+    r = upload_rays(c, n, o, d, tmax, da, db, dh);
+    if (!r) r = dev_alloc(c, dhit, (size_t)n * 16);
+    if (!r)
+    {
+        launch_trace_rays_closest(c->stream, trace_launch(c), root, RayQueue{(f4*)da.p, (f4*)db.p}, n, (uint32_t*)dh.p, (f4*)dhit.p);
+        std::vector<f4> h(n);
+        hipError_t e = hipMemcpyAsync(h.data(), dhit.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) r = fail(c, PT_ERR_HIP, hipGetErrorString(e));
+        else
+        {
+            const FlatScene& f = c->scene.flat;
+            const uint32_t mask = (1u << f.prim_bits) - 1u;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const uint32_t id = bits(h[i].w);
+                t[i] = h[i].x; u[i] = h[i].y; v[i] = h[i].z;
+                if (id == MISS_ID) { inst[i] = prim[i] = MISS_ID; t[i] = __builtin_inff(); u[i] = v[i] = 0; }
+                else
+                {
+                    inst[i] = (id >> f.prim_bits) - f.inst_base[which ? 1 : 0];
+                    prim[i] = f.tri_orig[id & mask];
+                }
+            }
+        }
+    }
+    dev_free(da); dev_free(db); dev_free(dh); dev_free(dhit);
+    return r;
+}
+
+int pt_trace_any(pt_ctx* c, int which, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* hit)
+{
+    if (!c || !o || !d || !tmax || !hit) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = upload_scene(c))) return r;
+    if (n == 0) return PT_OK;
+    const uint32_t root = which ? c->sv.lights_root : c->sv.world_root;
+    if (root == MISS_ID) { std::memset(hit, 0, n); return PT_OK; }
+    DevBuf da, db, dh, docc;
+    r = upload_rays(c, n, o, d, tmax, da, db, dh);
+    if (!r) r = dev_alloc(c, docc, (size_t)n * 4);
+    if (!r)
+    {
+        launch_trace_rays_any(c->stream, trace_launch(c), root, RayQueue{(f4*)da.p, (f4*)db.p}, n, (uint32_t*)dh.p, (uint32_t*)docc.p);
+        std::vector<uint32_t> h(n);
+        hipError_t e = hipMemcpyAsync(h.data(), docc.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) r = fail(c, PT_ERR_HIP, hipGetErrorString(e));
+        else
+            for (uint32_t i = 0; i < n; ++i) hit[i] = h[i] ? 1 : 0;
+    }
+    dev_free(da); dev_free(db); dev_free(dh); dev_free(docc);
+    return r;
+}
+
+int pt_ss_sobol(pt_ctx* c, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out)
+{
+    if (!c || !index || !seed || !out || n_points == 0) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    DevBuf di, ds, dout;
+    if ((r = dev_alloc(c, di, (size_t)n * 4)) || (r = dev_alloc(c, ds, (size_t)n * 4)) || (r = dev_alloc(c, dout, (size_t)n * 8))) return r;
+    HIPCHK(c, hipMemcpy(di.p, index, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(ds.p, seed, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_sobol_probe(c->stream, n_points, n, (const uint32_t*)di.p, (const uint32_t*)ds.p, (float*)dout.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    dev_free(di); dev_free(ds); dev_free(dout);
+    return PT_OK;
+}
+
+int pt_math_batch(pt_ctx* c, int fn, uint32_t n, const float* a, const float* b, float* o0, float* o1)
+{
+    if (!c || !a || !o0) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    DevBuf da, db, d0, d1;
+    if ((r = dev_alloc(c, da, (size_t)n * 4)) || (r = dev_alloc(c, db, (size_t)n * 4)) || (r = dev_alloc(c, d0, (size_t)n * 4)) ||
+        (r = dev_alloc(c, d1, (size_t)n * 4)))
+        return r;
+    HIPCHK(c, hipMemcpy(da.p, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (b) HIPCHK(c, hipMemcpy(db.p, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    else HIPCHK(c, hipMemset(db.p, 0, (size_t)n * 4));
+    HIPCHK(c, hipMemset(d1.p, 0, (size_t)n * 4));
+    launch_math_probe(c->stream, fn, n, (const float*)da.p, (const float*)db.p, (float*)d0.p, (float*)d1.p, c->cfg.seed);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(o0, d0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (o1) HIPCHK(c, hipMemcpy(o1, d1.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    dev_free(da); dev_free(db); dev_free(d0); dev_free(d1);
+    return PT_OK;
+}
+
+int pt_material_eval(pt_ctx* c, int material, uint32_t n, const float* incoming, const float* normal, const uint8_t* front, const uint32_t* pixel,
+                     const uint32_t* sample, uint32_t draws, float* out9)
+{
+    if (!c || !incoming || !normal || !front || !pixel || !sample || !out9) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (material < 0 || material >= (int)c->scene.materials.size()) return fail(c, PT_ERR_ARG, "material index");
+    int r;
+    if ((r = upload_scene(c))) return r;
+    DevBuf di, dn, df, dp, ds, dout;
+    if ((r = dev_alloc(c, di, (size_t)n * 12)) || (r = dev_alloc(c, dn, (size_t)n * 12)) || (r = dev_alloc(c, df, n)) ||
+        (r = dev_alloc(c, dp, (size_t)n * 4)) || (r = dev_alloc(c, ds, (size_t)n * 4)) || (r = dev_alloc(c, dout, (size_t)n * 36)))
+        return r;
+    HIPCHK(c, hipMemcpy(di.p, incoming, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn.p, normal, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(df.p, front, n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dp.p, pixel, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(ds.p, sample, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_material_probe(c->stream, c->sv, material, n, (const float*)di.p, (const float*)dn.p, (const uint8_t*)df.p, (const uint32_t*)dp.p,
+                          (const uint32_t*)ds.p, draws, c->cfg.seed, (float*)dout.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out9, dout.p, (size_t)n * 36, hipMemcpyDeviceToHost));
+    dev_free(di); dev_free(dn); dev_free(df); dev_free(dp); dev_free(ds); dev_free(dout);
+    return PT_OK;
+}
+
+// ---- host-builder introspection
+int pt_blas_count(pt_ctx* c) { return (c && c->scene.built) ? (int)c->scene.blas.size() : PT_ERR_STATE; }
+
+int pt_blas_dump(pt_ctx* c, int blas, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
+                 uint32_t* n_prim_ids, uint32_t* prim_ids, uint32_t cap_nodes, uint32_t cap_ids)
+{
+    if (!c || !c->scene.built) return PT_ERR_STATE;
+    if (blas < 0 || blas >= (int)c->scene.blas.size()) return PT_ERR_ARG;
+    const HostBlas& bl = c->scene.blas[blas];
+    *n_nodes = (uint32_t)bl.nodes.size();
+    *root = bl.root;
+    *n_prim_ids = (uint32_t)bl.prim_ids.size();
+    if (bl.nodes.size() > cap_nodes || bl.prim_ids.size() > cap_ids) return PT_ERR_ARG;
+    for (size_t i = 0; i < bl.nodes.size(); ++i)
+    {
+        std::memcpy(boxes6 + i * 6, &bl.nodes[i].box, 24);
+        kind[i] = bl.nodes[i].kind == NODE_BRANCH ? 0 : 1;
+        a[i] = bl.nodes[i].a;
+        b[i] = bl.nodes[i].b;
+    }
+    std::memcpy(prim_ids, bl.prim_ids.data(), bl.prim_ids.size() * 4);
+    return PT_OK;
+}
+
+int pt_tlas_dump(pt_ctx* c, int which, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b, uint32_t cap)
+{
+    if (!c || !c->scene.built) return PT_ERR_STATE;
+    const HostTlas& t = which ? c->scene.lights : c->scene.world;
+    *n_nodes = (uint32_t)t.nodes.size();
+    *root = t.root;
+    if (t.nodes.size() > cap) return PT_ERR_ARG;
+    for (size_t i = 0; i < t.nodes.size(); ++i)
+    {
+        std::memcpy(boxes6 + i * 6, &t.nodes[i].box, 24);
+        kind[i] = t.nodes[i].kind == NODE_BRANCH ? 0 : 1;
+        a[i] = t.nodes[i].a;
+        b[i] = t.nodes[i].b;
+    }
+    return PT_OK;
+}
+
+int pt_light_cdf(pt_ctx* c, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap)
+{
+    if (!c || !c->scene.built) return PT_ERR_STATE;
+    const auto& L = c->scene.light_items;
+    *n = (uint32_t)L.size();
+    *max_weight = c->scene.light_weight_sum;
+    if (L.size() > cap) return PT_ERR_ARG;
+    for (size_t i = 0; i < L.size(); ++i) { pdf[i] = L[i].pdf; cdf[i] = L[i].cdf; blas[i] = L[i].blas; prim[i] = L[i].prim; }
+    return PT_OK;
+}
+
+int pt_triangle_dump(pt_ctx* c, int blas, uint32_t prim, float out36[36])
+{
+    if (!c || !c->scene.built) return PT_ERR_STATE;
+    if (blas < 0 || blas >= (int)c->scene.blas.size() || prim >= c->scene.blas[blas].tris.size()) return PT_ERR_ARG;
+    const HostTriangle& t = c->scene.blas[blas].tris[prim];
+    std::memcpy(out36, &t.n0, 16);
+    std::memcpy(out36 + 4, &t.n1, 16);
+    std::memcpy(out36 + 8, &t.n2, 16);
+    std::memcpy(out36 + 12, t.p, 36);
+    std::memcpy(out36 + 21, t.n, 36);
+    for (int i = 30; i < 36; ++i) out36[i] = 0;
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx* c, pt_stats* out)
+{
+    if (!c || !out) return PT_ERR_ARG;
+    *out = c->stats;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_ctx* c)
+{
+    if (!c) return PT_ERR_ARG;
+    pt_stats keep = c->stats;
+    c->stats = pt_stats();
+    c->stats.scene_bytes = keep.scene_bytes;
+    c->stats.lds_scene = keep.lds_scene;
+    c->stats.stack_entries = keep.stack_entries;
+    c->stats.state_bytes = keep.state_bytes;
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,53 @@
+// Launch interface of the gfx950 kernels (pt_kernels.hip).  No launcher allocates, frees or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pt_types.h"
+
+namespace pt {
+
+struct TraceLaunch
+{
+    SceneView scene;
+    const void* blob;        // contiguous nodes | tri_isect | instances (device), copied to LDS when lds_scene
+    bool lds_scene;
+    uint32_t grid_blocks;    // persistent grid
+    uint32_t block_threads;  // 64..256
+};
+
+struct WavefrontBuffers
+{
+    PathState st;
+    RayQueue rq[2];       // world closest-hit rays, double buffered by bounce parity
+    RayQueue rq_shadow;   // explicit-light shadow rays
+    RayQueue rq_lchain[2]; // BSDF-sampled NEE rays, double buffered by bounce parity (the next shading pass re-reads directions)
+    f4* hits;             // world closest hits, dense by ray index
+    uint32_t* q_shade[Q_COUNT]; // Q_TERMINAL slot unused (see q_term)
+    uint32_t* q_term[2];  // terminal queue, double buffered by bounce parity
+    Counters* counters;   // [max_bounces + 2]
+};
+
+void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb);
+// closest hit against the world TLAS for bounce `b`: reads rq[b&1], writes hits + shade queues of row b
+void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
+// NEE rays produced by the shading of bounce `b` (counter row b)
+void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
+void launch_trace_lchain_closest(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
+void launch_trace_lchain_any(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
+// shading of bounce b for one queue class
+void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
+                  uint32_t grid_blocks);
+// accum[pixel] += sum over batch samples in order of (finalised rgb, 1); position/id of the last samples
+void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
+                       uint32_t write_position);
+void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out);
+
+// unit hooks
+void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits);
+void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded);
+void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy);
+void launch_math_probe(hipStream_t s, int fn, uint32_t n, const float* a, const float* b, float* o0, float* o1, uint64_t seed);
+void launch_material_probe(hipStream_t s, const SceneView& sv, int material, uint32_t n, const float* incoming, const float* normal,
+                           const uint8_t* front, const uint32_t* pixel, const uint32_t* sample, uint32_t draws, uint64_t seed, float* out9);
+
+} // namespace pt

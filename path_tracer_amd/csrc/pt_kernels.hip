@@ -1,0 +1,979 @@
+// gfx950 (MI355X, wave64) kernels of the wavefront path tracer.
+//
+//   k_generate      main.rs:186-199   seed draw, shuffled-scrambled Sobol jitter, camera ray
+//   k_closest       tlas.rs:66-110 + blas.rs:214-256 + boundingbox.rs:115-131 + primitive.rs:117-178
+//                   persistent-threads ordered traversal; BVH staged in LDS; per-lane stack in LDS;
+//                   ballot/mbcnt refill of idle lanes from the ray queue; material binning of the hits
+//   k_any           tlas.rs:111-144 + blas.rs:257-294   (shadow rays)
+//   k_shade<class>  integrator.rs:163-270 split per material class; NEE of the previous bounce is resolved first
+//   k_accumulate    integrator.rs:272-280 + accumulate.wgsl:20-23 in sample order
+//
+// Arithmetic: pt_math.h / pt_materials.h.  Built with -ffp-contract=off; v_min/v_max are used in the slab test only
+// where they provably equal the SSE select semantics of the reference (see slab()).
+#include "pt_kernels.h"
+#include "pt_materials.h"
+
+namespace pt {
+namespace {
+
+constexpr int kStepsPerRound = 6;  // traversal steps between refill checks
+constexpr int kRefillBelow = 40;   // refill idle lanes when at most this many lanes are still traversing
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// one atomic per wave; returns this lane's slot when pred is set
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred)
+{
+    const uint64_t m = __ballot(pred);
+    uint32_t pos = 0;
+    if (m != 0ull)
+    {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        pos = base + mbcnt64(m);
+    }
+    return pos;
+}
+
+__device__ __forceinline__ f3 xyz(const f4& v) { return f3{v.x, v.y, v.z}; }
+__device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
+
+// AABB::intersect / intersect_t (boundingbox.rs:97-131).  The reference's glam min/max are SSE selects
+// (second operand wins on NaN).  With t_max not NaN every second operand below is NaN-free, so IEEE minNum/maxNum
+// (v_min_f32/v_max_f32) return the same values; zero-sign differences cannot reach the result because t_smaller >= EPS.
+// Callers guarantee t_max is not NaN (NaN t_max makes every reference box test fail; handled at the call sites).
+__device__ __forceinline__ bool slab(const uint4 w0, const uint4 w1, const f3 o, const f3 inv, const float t_max, float& t_enter)
+{
+    const float t0x = (asf(w0.x) - o.x) * inv.x, t0y = (asf(w0.y) - o.y) * inv.y, t0z = (asf(w0.z) - o.z) * inv.z;
+    const float t1x = (asf(w1.x) - o.x) * inv.x, t1y = (asf(w1.y) - o.y) * inv.y, t1z = (asf(w1.z) - o.z) * inv.z;
+    const float sx = fminf(fmaxf(t0x, PT_EPSILON), fmaxf(t1x, PT_EPSILON));
+    const float sy = fminf(fmaxf(t0y, PT_EPSILON), fmaxf(t1y, PT_EPSILON));
+    const float sz = fminf(fmaxf(t0z, PT_EPSILON), fmaxf(t1z, PT_EPSILON));
+    const float bx = fmaxf(fminf(t0x, t_max), fminf(t1x, t_max));
+    const float by = fmaxf(fminf(t0y, t_max), fminf(t1y, t_max));
+    const float bz = fmaxf(fminf(t0z, t_max), fminf(t1z, t_max));
+    const float ts = fmaxf(fmaxf(sx, sz), fmaxf(sy, sz));
+    const float tb = fminf(fminf(bx, bz), fminf(by, bz));
+    t_enter = ts;
+    return ts <= tb;
+}
+
+__device__ __forceinline__ bool sign_differs(float a, float b) // a.signum() != b.signum()
+{
+    return __builtin_isunordered(a, b) || (((asu(a) ^ asu(b)) >> 31) != 0u);
+}
+
+// Triangle::intersect_naive on the pre-translated origin (primitive.rs:117-155)
+__device__ __forceinline__ bool tri_planes(const uint4 p0, const uint4 p1, const uint4 p2, const f3 o, const f3 d, const float t_max,
+                                           const float t_est, float& td, float& ud, float& vd, float& det)
+{
+    const f3 mo = fma3(d, bc3(t_est), o); // ray.at(t_estimate)
+    const float t_min = PT_EPSILON - t_est, t_mx = t_max - t_est;
+    const f4 n0{asf(p0.x), asf(p0.y), asf(p0.z), asf(p0.w)};
+    det = dot3(d, xyz(n0));
+    td = -dot4(f4{mo.x, mo.y, mo.z, -1.0f}, n0);
+    if (sign_differs(td - det * t_min, det * t_mx - td)) return false;
+    const f3 p = det * mo + td * d;
+    const f4 p4{p.x, p.y, p.z, det};
+    ud = dot4(p4, f4{asf(p1.x), asf(p1.y), asf(p1.z), asf(p1.w)});
+    if (sign_differs(ud, det - ud)) return false;
+    vd = dot4(p4, f4{asf(p2.x), asf(p2.y), asf(p2.z), asf(p2.w)});
+    if (sign_differs(vd, det - ud - vd)) return false;
+    return true;
+}
+
+struct Blob
+{
+    const uint4* nodes; // 2 words per node
+    const uint4* tris;  // 3 words per triangle
+    const uint4* inst;  // 7 words per instance
+};
+
+struct LaneRay { f3 o, d, inv; };
+
+// Ray::transform(inv_matrix)  ray.rs:22-28
+__device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, const LaneRay& w, uint32_t& root)
+{
+    const uint4* ip = bl.inst + 7u * inst;
+    const uint4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    LaneRay r;
+    r.o.x = ((asf(r0.x) * w.o.x + asf(r0.y) * w.o.y) + asf(r0.z) * w.o.z) + asf(r0.w);
+    r.o.y = ((asf(r1.x) * w.o.x + asf(r1.y) * w.o.y) + asf(r1.z) * w.o.z) + asf(r1.w);
+    r.o.z = ((asf(r2.x) * w.o.x + asf(r2.y) * w.o.y) + asf(r2.z) * w.o.z) + asf(r2.w);
+    r.d.x = (asf(r0.x) * w.d.x + asf(r0.y) * w.d.y) + asf(r0.z) * w.d.z;
+    r.d.y = (asf(r1.x) * w.d.x + asf(r1.y) * w.d.y) + asf(r1.z) * w.d.z;
+    r.d.z = (asf(r2.x) * w.d.x + asf(r2.y) * w.d.y) + asf(r2.z) * w.d.z;
+    r.inv = rcp3(r.d);
+    root = ip[6].x;
+    return r;
+}
+
+template <bool LDS_SCENE>
+__device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __restrict__ gblob, uint4* smem, uint32_t& words)
+{
+    Blob b;
+    if (LDS_SCENE)
+    {
+        words = sv.blob_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) smem[i] = gblob[i];
+        __syncthreads();
+        b.nodes = smem;
+        b.tris = smem + 2u * sv.n_nodes;
+        b.inst = smem + 2u * sv.n_nodes + 3u * sv.n_tris;
+    }
+    else
+    {
+        words = 0;
+        b.nodes = gblob;
+        b.tris = gblob + 2u * sv.n_nodes;
+        b.inst = gblob + 2u * sv.n_nodes + 3u * sv.n_tris;
+    }
+    return b;
+}
+
+enum { CLOSEST_WORLD = 0, CLOSEST_LIGHTS = 1, CLOSEST_HOOK = 2 };
+
+struct ClosestOut
+{
+    f4* hits;              // WORLD/HOOK: dense by ray index; LIGHTS: by path id
+    uint32_t* q_shade[Q_COUNT];
+    uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
+    uint32_t* n_light_hit;
+};
+
+// ------------------------------------------------------------------------------------------------ closest hit
+template <bool LDS_SCENE, int MODE>
+__global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
+                                                  const ClosestOut out)
+{
+    extern __shared__ uint4 smem[];
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
+    uint2* const stack = reinterpret_cast<uint2*>(smem + blob_words) + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint32_t n = *n_ptr;
+    const uint32_t prim_bits = sv.prim_bits;
+
+    bool active = false, pending = false, exhausted = false;
+    uint32_t ray_idx = 0, pid = 0;
+    LaneRay w{}, ob{};
+    float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
+    uint32_t bid = MISS_ID, sp = 0, blas_base = 0, inst = 0;
+    bool in_blas = false;
+
+    for (;;)
+    {
+        uint64_t act = __ballot(active);
+        const bool service = exhausted ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        if (service)
+        {
+            // ---- flush finished lanes
+            if (__ballot(pending) != 0ull)
+            {
+                if (MODE == CLOSEST_WORLD)
+                {
+                    uint32_t cls = Q_TERMINAL;
+                    if (pending && bid != MISS_ID) cls = bl.inst[7u * (bid >> prim_bits) + 6u].w;
+#pragma unroll
+                    for (uint32_t c = 0; c < Q_COUNT; ++c)
+                    {
+                        const bool mine = pending && cls == c;
+                        const uint32_t pos = wave_append(out.n_shade + c, mine);
+                        if (mine) out.q_shade[c][pos] = ray_idx;
+                    }
+                    if (pending) out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                }
+                else if (MODE == CLOSEST_LIGHTS)
+                {
+                    const uint64_t hm = __ballot(pending && bid != MISS_ID);
+                    if (hm != 0ull && lane_id() == (uint32_t)(__ffsll((long long)hm) - 1)) atomicAdd(out.n_light_hit, (uint32_t)__popcll(hm));
+                    if (pending) out.hits[pid] = f4{bt, bu, bv, asf(bid)};
+                }
+                else
+                {
+                    if (pending) out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                }
+                pending = false;
+            }
+            if (exhausted) break;
+            // ---- refill idle lanes from the queue (one atomic per wave)
+            const uint64_t idle = ~act;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane_id() == 0u) base = atomicAdd(head, n_idle);
+            base = __shfl(base, 0);
+            const uint32_t mine = base + mbcnt64(idle);
+            if (!active && mine < n)
+            {
+                const f4 a = ra[mine], b = rb[mine];
+                ray_idx = mine;
+                pid = asu(b.w);
+                w.o = xyz(a);
+                w.d = xyz(b);
+                w.inv = rcp3(w.d);
+                t_max = a.w;
+                bid = MISS_ID;
+                bt = asf(0x7f800000u);
+                bu = 0.0f;
+                bv = 0.0f;
+                in_blas = false;
+                sp = 0;
+                // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
+                float te;
+                const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                if (ok)
+                {
+                    stack[0] = make_uint2(root, 0u);
+                    sp = 1;
+                    active = true;
+                }
+                else { pending = true; }
+            }
+            if (base + n_idle >= n) exhausted = true;
+            act = __ballot(active);
+            if (act == 0ull) continue; // either flushes the just-missed lanes and refills again, or exits
+        }
+
+#pragma unroll 1
+        for (int it = 0; it < kStepsPerRound; ++it)
+        {
+            if (!active) continue;
+            if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
+            if (sp == 0u)
+            {
+                active = false;
+                pending = true;
+                continue;
+            }
+            sp -= 1u;
+            const uint2 e = stack[sp * stride];
+            if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
+            const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
+            const uint32_t a = nw[3];
+            uint32_t b = nw[7];
+            const uint32_t kind = b >> NODE_KIND_SHIFT;
+            b &= NODE_PAYLOAD_MASK;
+            if (kind == NODE_BRANCH)
+            {
+                // push_to_stack  blas.rs:133-162
+                const uint4 l0 = bl.nodes[2u * a], l1 = bl.nodes[2u * a + 1u];
+                const uint4 r0 = bl.nodes[2u * b], r1 = bl.nodes[2u * b + 1u];
+                const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
+                float tl, tr;
+                const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                if (hl && hr)
+                {
+                    const bool left_near = tl < tr;
+                    stack[sp * stride] = left_near ? make_uint2(b, asu(tr)) : make_uint2(a, asu(tl));
+                    stack[(sp + 1u) * stride] = left_near ? make_uint2(a, asu(tl)) : make_uint2(b, asu(tr));
+                    sp += 2u;
+                }
+                else if (hl) { stack[sp * stride] = make_uint2(a, asu(tl)); sp += 1u; }
+                else if (hr) { stack[sp * stride] = make_uint2(b, asu(tr)); sp += 1u; }
+            }
+            else if (kind == NODE_TRIS)
+            {
+                const float t_est = asf(e.y);
+                for (uint32_t k = 0; k < b; ++k)             // blas.rs:230-251
+                {
+                    const uint4* tp = bl.tris + 3u * (a + k);
+                    float td, ud, vd, det;
+                    if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_est, td, ud, vd, det))
+                    {
+                        // primitive.rs:158-170: (t,u,v) = xyz / det ; t += t_estimate
+                        bt = td / det + t_est;
+                        bu = ud / det;
+                        bv = vd / det;
+                        t_max = bt;
+                        bid = (inst << prim_bits) | (a + k);
+                        if (bt != bt) { sp = 0u; in_blas = false; break; } // NaN t_max: nothing else can be accepted
+                    }
+                }
+            }
+            else
+            {
+                // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99
+                uint32_t blas_root;
+                ob = to_object(bl, a, w, blas_root);
+                inst = a;
+                in_blas = true;
+                blas_base = sp;
+                stack[sp * stride] = make_uint2(blas_root, 0u); // root pushed without a box test  blas.rs:217
+                sp += 1u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ any hit
+enum { ANY_SHADOW = 0, ANY_LCHAIN = 1, ANY_HOOK = 2 };
+
+template <bool LDS_SCENE, int MODE>
+__global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
+                                              const f4* __restrict__ lhit, uint32_t* __restrict__ occluded)
+{
+    extern __shared__ uint4 smem[];
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
+    uint32_t* const stack = reinterpret_cast<uint32_t*>(smem + blob_words) + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint32_t n = *n_ptr;
+
+    bool active = false, exhausted = false;
+    uint32_t out_idx = 0;
+    LaneRay w{}, ob{};
+    float t_max = 0.0f;
+    uint32_t sp = 0, blas_base = 0;
+    bool in_blas = false;
+
+    for (;;)
+    {
+        uint64_t act = __ballot(active);
+        const bool service = exhausted ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        if (service)
+        {
+            if (exhausted) break;
+            const uint64_t idle = ~act;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane_id() == 0u) base = atomicAdd(head, n_idle);
+            base = __shfl(base, 0);
+            const uint32_t mine = base + mbcnt64(idle);
+            if (!active && mine < n)
+            {
+                const f4 a = ra[mine], b = rb[mine];
+                const uint32_t pid = asu(b.w);
+                out_idx = (MODE == ANY_HOOK) ? mine : pid;
+                w.o = xyz(a);
+                w.d = xyz(b);
+                w.inv = rcp3(w.d);
+                t_max = a.w;
+                bool go = true;
+                if (MODE == ANY_LCHAIN)
+                {
+                    // integrator.rs:100-103: only rays whose lights-TLAS closest hit exists; t_max = light_t * (1 - EPS)
+                    const f4 lh = lhit[pid];
+                    go = asu(lh.w) != MISS_ID;
+                    t_max = lh.x * (1.0f - PT_EPSILON);
+                }
+                if (go)
+                {
+                    if (t_max == t_max)
+                    {
+                        stack[0] = root;
+                        sp = 1;
+                        in_blas = false;
+                        active = true;
+                    }
+                    else { occluded[out_idx] = 0u; } // NaN t_max: every reference box test fails -> not occluded
+                }
+            }
+            if (base + n_idle >= n) exhausted = true;
+            act = __ballot(active);
+            if (act == 0ull) continue;
+        }
+
+#pragma unroll 1
+        for (int it = 0; it < kStepsPerRound; ++it)
+        {
+            if (!active) continue;
+            if (in_blas && sp == blas_base) in_blas = false;
+            if (sp == 0u)
+            {
+                active = false;
+                occluded[out_idx] = 0u;
+                continue;
+            }
+            sp -= 1u;
+            const uint32_t id = stack[sp * stride];
+            const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
+            float t_enter;
+            const bool hit = in_blas ? slab(n0, n1, ob.o, ob.inv, t_max, t_enter) : slab(n0, n1, w.o, w.inv, t_max, t_enter);
+            if (!hit) continue;                              // tlas.rs:118-121 / blas.rs:264
+            const uint32_t a = n0.w, kind = n1.w >> NODE_KIND_SHIFT, b = n1.w & NODE_PAYLOAD_MASK;
+            if (kind == NODE_BRANCH)
+            {
+                stack[sp * stride] = a;                      // left then right: right is popped first
+                stack[(sp + 1u) * stride] = b;
+                sp += 2u;
+            }
+            else if (kind == NODE_TRIS)
+            {
+                for (uint32_t k = 0; k < b; ++k)             // intersect_bool  primitive.rs:181-189
+                {
+                    const uint4* tp = bl.tris + 3u * (a + k);
+                    float td, ud, vd, det;
+                    if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
+                    {
+                        active = false;
+                        occluded[out_idx] = 1u;
+                        break;
+                    }
+                }
+            }
+            else
+            {
+                uint32_t blas_root;
+                ob = to_object(bl, a, w, blas_root);
+                in_blas = true;
+                blas_base = sp;
+                stack[sp * stride] = blas_root;              // BLAS root IS box-tested on pop  blas.rs:262-264
+                sp += 1u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ path bookkeeping
+struct PixelId { uint32_t gpixel, sample, lpixel; };
+
+__device__ __forceinline__ uint32_t global_row(const RenderParams& rp, uint32_t ly)
+{
+    return ((ly / rp.strip_rows) * rp.world_size + rp.rank) * rp.strip_rows + (ly % rp.strip_rows);
+}
+__device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t pid)
+{
+    const uint32_t s = pid / rp.local_pixels, lp = pid - s * rp.local_pixels;
+    const uint32_t ly = lp / rp.width, x = lp - ly * rp.width;
+    return PixelId{global_row(rp, ly) * rp.width + x, rp.first_sample + s, lp};
+}
+
+// main.rs:186-199
+__global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const CameraView cam, const PathState st, const RayQueue rq, Counters* ctr)
+{
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid == 0u) ctr[0].n_closest = rp.n_paths;
+    if (pid >= rp.n_paths) return;
+    const PixelId px = path_pixel(rp, pid);
+    Stream rng{stream_key(rp.seed, px.gpixel, px.sample), 0u};
+    const uint32_t seed = rng.u32();                                       // main.rs:193
+    float jx, jy;
+    ss_sobol(rp.n_sobol, px.sample, seed, &jx, &jy);                       // main.rs:194
+    const float ox = jx - 0.5f, oy = jy - 0.5f;
+    const uint32_t gx = px.gpixel % rp.width, gy = px.gpixel / rp.width;
+    const float u = ((float)gx + ox) / (float)rp.width;                    // main.rs:196
+    const float v = ((float)gy + oy) / (float)rp.height;                   // main.rs:197
+    // Camera::create_ray  camera.rs:94-105  (Mat4::project_point3, then normalise)
+    const float nx = u * 2.0f - 1.0f, ny = v * 2.0f - 1.0f, nz = 0.0f;
+    const float* M = cam.ray_matrix;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        float t = M[i] * nx;
+        t = M[4 + i] * ny + t;
+        t = M[8 + i] * nz + t;
+        t = M[12 + i] + t;
+        r[i] = t;
+    }
+    const float rw = 1.0f / r[3];
+    const f3 eye{cam.eye[0], cam.eye[1], cam.eye[2]};
+    const f3 dir = unit3(f3{r[0] * rw, r[1] * rw, r[2] * rw} - eye);
+    rq.a[pid] = f4{eye.x, eye.y, eye.z, asf(0x7f800000u)};
+    rq.b[pid] = f4{dir.x, dir.y, dir.z, asf(pid)};
+    st.pw[pid] = f4{1.0f, 1.0f, 1.0f, asf(rng.k)};
+    st.acc[pid] = f4{0.0f, 0.0f, 0.0f, asf(0u)};
+    const f3 far = fma3(dir, bc3(1e5f), eye);                              // integrator.rs:156
+    st.first_pos[pid] = f4{far.x, far.y, far.z, 1e5f};
+    st.first_id[pid] = 255u;                                               // integrator.rs:157
+}
+
+struct ShadeIO
+{
+    PathState st;
+    RayQueue rq_in, rq_out, rq_shadow, rq_lchain_prev, rq_lchain;
+    const f4* hits;
+    const uint32_t* entries;
+    uint32_t* q_term_next;
+    Counters* ctr;     // row of this bounce
+    Counters* ctr_next;
+};
+
+// MIS power heuristic  integrator.rs:22
+__device__ __forceinline__ float mis2(float f, float g) { return sq(f) / (sq(f) + sq(g)); }
+
+// shading normal of a hit: Triangle::get_normal + face-forward in object space (primitive.rs:57-63,161-165),
+// then the deferred instance transform (tlas.rs:105)
+__device__ __forceinline__ f3 hit_normal(const SceneView& sv, uint32_t inst, uint32_t tri, float u, float v, f3 dir_world, bool& front)
+{
+    const DTriVerts tv = sv.tri_shade[tri];
+    const float wgt = 1.0f - u - v;
+    const m33 nm{xyz(tv.a), xyz(tv.b), xyz(tv.c)};
+    f3 n = unit3(mul(nm, f3{wgt, u, v}));
+    const DInstance& in = sv.instances[inst];
+    const f3 d_obj{(in.inv[0] * dir_world.x + in.inv[1] * dir_world.y) + in.inv[2] * dir_world.z,
+                   (in.inv[4] * dir_world.x + in.inv[5] * dir_world.y) + in.inv[6] * dir_world.z,
+                   (in.inv[8] * dir_world.x + in.inv[9] * dir_world.y) + in.inv[10] * dir_world.z};
+    front = dot3(d_obj, n) < 0.0f;
+    if (!front) n = -n;
+    return f3{(in.fwd[0] * n.x + in.fwd[1] * n.y) + in.fwd[2] * n.z, (in.fwd[4] * n.x + in.fwd[5] * n.y) + in.fwd[6] * n.z,
+              (in.fwd[8] * n.x + in.fwd[9] * n.y) + in.fwd[10] * n.z};
+}
+
+// add the previous bounce's direct-light estimate: accumulated += path_weight * (explicit + bsdf)   integrator.rs:231-234
+__device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& io, uint32_t pid, f3& acc, uint32_t& flags)
+{
+    if (!(flags & FLAG_NEE_PENDING)) return;
+    const f4 e4 = io.st.nee_e[pid];
+    const f4 pw4 = io.st.nee_pw[pid];
+    f3 e = xyz(e4);
+    if (io.st.occl_e[pid] != 0u) e = f3{0.0f, 0.0f, 0.0f};               // integrator.rs:55-56,73
+    f3 s{0.0f, 0.0f, 0.0f};
+    if (flags & FLAG_BSDF_CAST)
+    {
+        const f4 lh = io.st.lhit[pid];
+        const uint32_t lid = asu(lh.w);
+        if (lid != MISS_ID && io.st.occl_b[pid] == 0u && pw4.w > 0.0f)     // integrator.rs:100,103,108
+        {
+            const f4 b4 = io.st.nee_b[pid];
+            const uint32_t inst = lid >> sv.prim_bits, tri = lid & ((1u << sv.prim_bits) - 1u);
+            const DInstance& in = sv.instances[inst];
+            const DMaterial& lm = sv.materials[in.material];
+            const f3 emitted{lm.colour[0], lm.colour[1], lm.colour[2]};
+            const DTriIsect ti = sv.tri_isect[tri];
+            const float area = 0.5f * len3(xyz(ti.n0));                    // primitive.rs:94
+            const float sample_pdf = (area * len3(emitted) / sv.light_weight_sum) / area; // light_sampler.rs:39, integrator.rs:111
+            const f3 dir = xyz(io.rq_lchain_prev.b[asu(e4.w)]);
+            bool ff;
+            const f3 ln = hit_normal(sv, inst, tri, lh.y, lh.z, dir, ff);
+            const float cosine = fabsf(dot3(dir, ln));
+            const float light_pdf = sample_pdf * (lh.x * lh.x / cosine);   // integrator.rs:115
+            const float weight = mis2(pw4.w, light_pdf);
+            s = emitted * weight * b4.w * xyz(b4) / pw4.w;                 // integrator.rs:119-123
+        }
+    }
+    acc = acc + xyz(pw4) * (e + s);
+    flags &= ~(FLAG_NEE_PENDING | FLAG_BSDF_CAST);
+}
+
+// ------------------------------------------------------------------------------------------------ shading
+// Q_TERMINAL: misses (integrator.rs:254-269), emissive hits (:207-214) and paths that already ended but still owe an NEE resolve.
+__global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
+{
+    const uint32_t n = io.ctr->n_shade[Q_TERMINAL];
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
+    {
+        const uint32_t entry = io.entries[idx];
+        const bool dead = (entry & ENTRY_DEAD) != 0u;
+        uint32_t pid;
+        f4 ra{}, rb{}, hit{};
+        if (dead) pid = entry & ~ENTRY_DEAD;
+        else
+        {
+            ra = io.rq_in.a[entry];
+            rb = io.rq_in.b[entry];
+            hit = io.hits[entry];
+            pid = asu(rb.w);
+        }
+        f4 acc4 = io.st.acc[pid];
+        f3 acc = xyz(acc4);
+        uint32_t flags = asu(acc4.w);
+        resolve_nee(sv, io, pid, acc, flags);
+        if (!dead)
+        {
+            const f3 pw = xyz(io.st.pw[pid]);
+            const uint32_t hid = asu(hit.w);
+            if (hid == MISS_ID) { acc = acc + f3{0.006f, 0.006f, 0.006f} * pw; }     // integrator.rs:263-266
+            else
+            {
+                const uint32_t inst = hid >> sv.prim_bits;
+                const DInstance& in = sv.instances[inst];
+                if (bounce == 0u)                                                     // integrator.rs:181-185
+                {
+                    const f3 p = fma3(xyz(rb), bc3(hit.x), xyz(ra));
+                    io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
+                    io.st.first_id[pid] = in.blas & 0xffu;
+                }
+                const DMaterial& m = sv.materials[in.material];
+                if (!rp.enable_nee || (flags & FLAG_LAST_DELTA) || bounce == 0u)       // integrator.rs:209-212
+                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
+            }
+        }
+        io.st.acc[pid] = f4{acc.x, acc.y, acc.z, asf(flags)};
+    }
+}
+
+// Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
+template <uint32_t QCLASS>
+__global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
+{
+    const uint32_t n = io.ctr->n_shade[QCLASS];
+    const uint32_t total = ((n + 63u) / 64u) * 64u; // whole waves take part in the queue appends
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+    {
+        const bool valid = idx < n;
+        bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false;
+        f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
+        uint32_t pid = 0, flags = 0;
+        f3 acc{}, pw{};
+        f4 nee_e{}, nee_pw{}, nee_b{};
+        uint32_t draws = 0;
+        if (valid)
+        {
+            const uint32_t entry = io.entries[idx];
+            const f4 ra = io.rq_in.a[entry], rb = io.rq_in.b[entry], hit = io.hits[entry];
+            pid = asu(rb.w);
+            const f4 acc4 = io.st.acc[pid], pw4 = io.st.pw[pid];
+            acc = xyz(acc4);
+            flags = asu(acc4.w);
+            pw = xyz(pw4);
+            resolve_nee(sv, io, pid, acc, flags);
+
+            const f3 ro = xyz(ra), rd = xyz(rb);
+            const uint32_t hid = asu(hit.w);
+            const uint32_t inst = hid >> sv.prim_bits, tri = hid & ((1u << sv.prim_bits) - 1u);
+            const DInstance& in = sv.instances[inst];
+            const MatView mat = load_material(sv.materials, in.material);
+            bool front;
+            const f3 normal = hit_normal(sv, inst, tri, hit.y, hit.z, rd, front);
+            const f3 p = fma3(rd, bc3(hit.x), ro);                                     // r.at(hit_info.t)
+            if (bounce == 0u)                                                          // integrator.rs:181-185
+            {
+                io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
+                io.st.first_id[pid] = in.blas & 0xffu;
+            }
+            const PixelId px = path_pixel(rp, pid);
+            Stream rng{stream_key(rp.seed, px.gpixel, px.sample), asu(pw4.w)};
+            const f3 wi = -rd;                                                         // integrator.rs:187
+            const bool is_delta = mat_is_delta(mat.kind);
+
+            if (rp.enable_nee && !is_delta)                                            // integrator.rs:231
+            {
+                // ---- estimate_direct_explicit  integrator.rs:25-74
+                {
+                    const float x = rng.f32();                                         // light_sampler.rs:33
+                    // binary_search_by(total_cmp): for a non-decreasing cdf Ok(i)/Err(i) = number of entries below x
+                    uint32_t li = 0, hi = sv.n_lights;
+                    const int32_t xk = total_order_key(x);
+                    while (li < hi)
+                    {
+                        const uint32_t mid = (li + hi) >> 1;
+                        if (total_order_key(sv.lights[mid].cdf) < xk) li = mid + 1u; else hi = mid;
+                    }
+                    if (li >= sv.n_lights) li = sv.n_lights - 1u;                       // clamp (reference would index out of bounds)
+                    const DLight L = sv.lights[li];
+                    float lu = rng.f32();                                              // primitive.rs:81-88
+                    float lv = rng.f32();
+                    if (lu + lv > 1.0f) { lu = 1.0f - lu; lv = 1.0f - lv; }
+                    const float lw = 1.0f - lu - lv;
+                    const DTriVerts lp = sv.tri_pos[L.tri], ln = sv.tri_shade[L.tri];
+                    const f3 point = mul(m33{xyz(lp.a), xyz(lp.b), xyz(lp.c)}, f3{lw, lu, lv});
+                    const f3 lnormal = unit3(mul(m33{xyz(ln.a), xyz(ln.b), xyz(ln.c)}, f3{lw, lu, lv}));
+                    const f3 d = point - p;
+                    const float dist2 = len_sq(d);
+                    const float dist = sqrtf(dist2);
+                    const f3 dir = unit3(d);
+                    f3 ce{0.0f, 0.0f, 0.0f};
+                    if (dot3(dir, normal) > 0.0f)                                      // integrator.rs:55
+                    {
+                        const BsdfSample bp = mat_bsdf_pdf(mat, wi, dir, normal, front);
+                        const DTriIsect ti = sv.tri_isect[L.tri];
+                        const float sample_pdf = L.pdf / (0.5f * len3(xyz(ti.n0)));    // integrator.rs:61
+                        const float cosine = fabsf(dot3(dir, lnormal));
+                        const float light_pdf = sample_pdf * (dist2 / cosine);         // integrator.rs:65
+                        const float weight = mis2(light_pdf, bp.pdf);
+                        const DMaterial& lm = sv.materials[L.material];
+                        ce = f3{lm.colour[0], lm.colour[1], lm.colour[2]} * weight * mat_weakening(mat.kind, dir, normal) * bp.bsdf / light_pdf;
+                        want_shadow = true;
+                        sh_a = f4{p.x, p.y, p.z, (1.0f - PT_EPSILON) * dist};          // integrator.rs:56
+                        sh_b = f4{dir.x, dir.y, dir.z, asf(pid)};
+                    }
+                    nee_e = f4{ce.x, ce.y, ce.z, 0.0f};
+                }
+                // ---- estimate_direct_bsdf  integrator.rs:77-130
+                {
+                    const f3 dir = mat_scatter(mat, rng, rd, normal, front);
+                    if (dot3(dir, normal) > 0.0f)                                      // integrator.rs:96
+                    {
+                        const BsdfSample bp = mat_bsdf_pdf(mat, wi, dir, normal, front);
+                        nee_b = f4{bp.bsdf.x, bp.bsdf.y, bp.bsdf.z, mat_weakening(mat.kind, dir, normal)};
+                        nee_pw.w = bp.pdf;
+                        want_lchain = true;
+                        lc_a = f4{p.x, p.y, p.z, asf(0x7f800000u)};
+                        lc_b = f4{dir.x, dir.y, dir.z, asf(pid)};
+                        flags |= FLAG_BSDF_CAST;
+                    }
+                }
+                nee_pw.x = pw.x; nee_pw.y = pw.y; nee_pw.z = pw.z;
+                flags |= FLAG_NEE_PENDING;
+            }
+
+            // ---- continuation  integrator.rs:236-251
+            const f3 ndir = mat_scatter(mat, rng, rd, normal, front);
+            const BsdfSample info = mat_bsdf_pdf(mat, wi, ndir, normal, front);
+            bool alive = !(info.pdf < 0.0f);                                           // MIN_PDF = 0  integrator.rs:243
+            if (alive)
+            {
+                pw = pw * (mat_weakening(mat.kind, ndir, normal) * info.bsdf / info.pdf); // integrator.rs:249
+                flags = is_delta ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
+                const uint32_t nb = bounce + 1u;
+                if (nb > rp.max_bounces) alive = false;                                 // for b in 0..=max_bounces
+                else if (nb > 3u)                                                       // Russian roulette of the next iteration  integrator.rs:166-177
+                {
+                    const float survive = min_num(hmax3(pw), 0.9999f);
+                    if (rng.f32() > survive) alive = false;
+                    else pw = pw / survive;
+                }
+            }
+            draws = rng.k;
+            if (alive)
+            {
+                want_next = true;
+                nx_a = f4{p.x, p.y, p.z, asf(0x7f800000u)};
+                nx_b = f4{ndir.x, ndir.y, ndir.z, asf(pid)};
+            }
+            else { want_dead = (flags & FLAG_NEE_PENDING) != 0u; }
+        }
+        // ---- wave-aggregated queue appends (all lanes of the wave reach these)
+        const uint32_t ps = wave_append(&io.ctr->n_shadow, want_shadow);
+        if (want_shadow) { io.rq_shadow.a[ps] = sh_a; io.rq_shadow.b[ps] = sh_b; }
+        const uint32_t pl = wave_append(&io.ctr->n_lchain, want_lchain);
+        if (want_lchain) { io.rq_lchain.a[pl] = lc_a; io.rq_lchain.b[pl] = lc_b; nee_e.w = asf(pl); }
+        const uint32_t pn = wave_append(&io.ctr_next->n_closest, want_next);
+        if (want_next) { io.rq_out.a[pn] = nx_a; io.rq_out.b[pn] = nx_b; }
+        const uint32_t pd = wave_append(&io.ctr_next->n_shade[Q_TERMINAL], want_dead);
+        if (want_dead) io.q_term_next[pd] = pid | ENTRY_DEAD;
+        if (valid)
+        {
+            io.st.pw[pid] = f4{pw.x, pw.y, pw.z, asf(draws)};
+            io.st.acc[pid] = f4{acc.x, acc.y, acc.z, asf(flags)};
+            if (flags & FLAG_NEE_PENDING)
+            {
+                io.st.nee_e[pid] = nee_e;
+                io.st.nee_pw[pid] = nee_pw;
+                if (flags & FLAG_BSDF_CAST) io.st.nee_b[pid] = nee_b;
+            }
+        }
+    }
+}
+
+// integrator.rs:272-280: finite check, clamp_length_max(100), alpha 1
+__device__ __forceinline__ f3 finalise(f3 acc)
+{
+    if (!finite3(acc)) return f3{0.0f, 0.0f, 0.0f};
+    return clamp_len_max(acc, 100.0f);
+}
+
+// accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206
+__global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const PathState st, f4* accum, f4* position, uint32_t* id,
+                                                     const uint32_t write_position)
+{
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= rp.local_pixels) return;
+    f4 a = accum[lp];
+    uint32_t idv = id[lp];
+    for (uint32_t s = 0; s < rp.batch_samples; ++s)
+    {
+        const uint32_t pid = s * rp.local_pixels + lp;
+        const f3 c = finalise(xyz(st.acc[pid]));
+        a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
+        idv = (idv << 16) | st.first_id[pid];
+    }
+    accum[lp] = a;
+    id[lp] = idv;
+    if (write_position) position[lp] = st.first_pos[(rp.batch_samples - 1u) * rp.local_pixels + lp];
+}
+
+__global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, const PathState st, f4* out)
+{
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= rp.n_paths) return;
+    const f3 c = finalise(xyz(st.acc[pid]));
+    out[pid] = f4{c.x, c.y, c.z, 1.0f};
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+__global__ void k_sobol_probe(uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ss_sobol(n_points, index[i], seed[i], &out[2 * i], &out[2 * i + 1]);
+}
+__global__ void k_math_probe(int fn, uint32_t n, const float* a, const float* b, float* o0, float* o1, uint64_t seed)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (fn)
+    {
+    case 0: sincos_det(a[i], &o0[i], &o1[i]); break;
+    case 1: o0[i] = exp_det(a[i]); break;
+    case 2: o0[i] = ln_det(a[i]); break;
+    case 3: o0[i] = hypot_det(a[i], b[i]); break;
+    case 4: o0[i] = a[i] / b[i]; break;
+    case 5: o0[i] = sqrtf(a[i]); break;
+    case 6: o0[i] = tan_det(a[i]); break;
+    case 7:
+    {
+        Stream r{stream_key(seed, asu(a[i]), asu(b[i])), 0u};
+        o0[i] = asf(r.u32());
+        o1[i] = r.f32();
+        break;
+    }
+    }
+}
+__global__ void k_material_probe(const SceneView sv, int material, uint32_t n, const float* incoming, const float* normal, const uint8_t* front,
+                                 const uint32_t* pixel, const uint32_t* sample, uint32_t draws, uint64_t seed, float* out9)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MatView m = load_material(sv.materials, (uint32_t)material);
+    Stream rng{stream_key(seed, pixel[i], sample[i]), draws};
+    const f3 in{incoming[3 * i], incoming[3 * i + 1], incoming[3 * i + 2]}, nn{normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+    const bool ff = front[i] != 0;
+    const f3 wo = mat_scatter(m, rng, in, nn, ff);
+    const BsdfSample bp = mat_bsdf_pdf(m, -in, wo, nn, ff);
+    float* o = out9 + 9 * i;
+    o[0] = wo.x; o[1] = wo.y; o[2] = wo.z;
+    o[3] = bp.bsdf.x; o[4] = bp.bsdf.y; o[5] = bp.bsdf.z;
+    o[6] = bp.pdf;
+    o[7] = mat_weakening(m.kind, wo, nn);
+    o[8] = (float)(rng.k - draws);
+}
+
+size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
+{
+    const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
+    return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4);
+}
+
+} // namespace
+
+// ================================================================================================ launchers
+void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb)
+{
+    const uint32_t blocks = (rp.n_paths + 255u) / 256u;
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, wb.rq[0], wb.counters);
+}
+
+template <int MODE>
+static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
+                                const ClosestOut& out)
+{
+    const size_t lds = trace_lds_bytes(tl, true);
+    if (tl.lds_scene)
+        hipLaunchKernelGGL((k_closest<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a,
+                           rq.b, n_ptr, head, out);
+    else
+        hipLaunchKernelGGL((k_closest<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a,
+                           rq.b, n_ptr, head, out);
+}
+template <int MODE>
+static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
+                            const f4* lhit, uint32_t* occluded)
+{
+    const size_t lds = trace_lds_bytes(tl, false);
+    if (tl.lds_scene)
+        hipLaunchKernelGGL((k_any<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
+                           n_ptr, head, lhit, occluded);
+    else
+        hipLaunchKernelGGL((k_any<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
+                           n_ptr, head, lhit, occluded);
+}
+
+void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+{
+    Counters* row = wb.counters + b;
+    ClosestOut out{};
+    out.hits = wb.hits;
+    for (uint32_t c = 0; c < Q_COUNT; ++c) out.q_shade[c] = wb.q_shade[c];
+    out.q_shade[Q_TERMINAL] = wb.q_term[b & 1u];
+    out.n_shade = row->n_shade;
+    out.n_light_hit = nullptr;
+    launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, &row->head_closest, out);
+}
+void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+{
+    Counters* row = wb.counters + b;
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, nullptr, wb.st.occl_e);
+}
+void launch_trace_lchain_closest(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+{
+    Counters* row = wb.counters + b;
+    ClosestOut out{};
+    out.hits = wb.st.lhit;
+    out.n_shade = nullptr;
+    out.n_light_hit = &row->n_lchain_hit;
+    launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
+}
+void launch_trace_lchain_any(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+{
+    Counters* row = wb.counters + b;
+    launch_any_impl<ANY_LCHAIN>(s, tl, tl.scene.world_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain_any, wb.st.lhit, wb.st.occl_b);
+}
+
+void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
+                  uint32_t grid_blocks)
+{
+    ShadeIO io{};
+    io.st = wb.st;
+    io.rq_in = wb.rq[b & 1u];
+    io.rq_out = wb.rq[(b + 1u) & 1u];
+    io.rq_shadow = wb.rq_shadow;
+    io.rq_lchain = wb.rq_lchain[b & 1u];
+    io.rq_lchain_prev = wb.rq_lchain[(b + 1u) & 1u];
+    io.hits = wb.hits;
+    io.entries = qclass == Q_TERMINAL ? wb.q_term[b & 1u] : wb.q_shade[qclass];
+    io.q_term_next = wb.q_term[(b + 1u) & 1u];
+    io.ctr = wb.counters + b;
+    io.ctr_next = wb.counters + b + 1u;
+    switch (qclass)
+    {
+    case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    case Q_LAMBERT: hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    case Q_SPECULAR: hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    case Q_DIELECTRIC: hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    case Q_GGX: hipLaunchKernelGGL((k_shade_surface<Q_GGX>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    default: break;
+    }
+}
+
+void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
+                       uint32_t write_position)
+{
+    const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, wb.st, accum, position, id, write_position);
+}
+void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)
+{
+    const uint32_t blocks = (rp.n_paths + 255u) / 256u;
+    hipLaunchKernelGGL(k_store_samples, dim3(blocks), dim3(256), 0, s, rp, wb.st, out);
+}
+
+void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits)
+{
+    // head[0] = cursor (zeroed by the caller), head[1] = n
+    (void)n;
+    ClosestOut out{};
+    out.hits = hits;
+    launch_closest_impl<CLOSEST_HOOK>(s, tl, root, rq, head + 1, head, out);
+}
+void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded)
+{
+    (void)n;
+    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, nullptr, occluded);
+}
+void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy)
+{
+    hipLaunchKernelGGL(k_sobol_probe, dim3((n + 255u) / 256u), dim3(256), 0, s, n_points, n, index, seed, out_xy);
+}
+void launch_math_probe(hipStream_t s, int fn, uint32_t n, const float* a, const float* b, float* o0, float* o1, uint64_t seed)
+{
+    hipLaunchKernelGGL(k_math_probe, dim3((n + 255u) / 256u), dim3(256), 0, s, fn, n, a, b, o0, o1, seed);
+}
+void launch_material_probe(hipStream_t s, const SceneView& sv, int material, uint32_t n, const float* incoming, const float* normal,
+                           const uint8_t* front, const uint32_t* pixel, const uint32_t* sample, uint32_t draws, uint64_t seed, float* out9)
+{
+    hipLaunchKernelGGL(k_material_probe, dim3((n + 255u) / 256u), dim3(256), 0, s, sv, material, n, incoming, normal, front, pixel, sample, draws, seed,
+                       out9);
+}
+
+} // namespace pt

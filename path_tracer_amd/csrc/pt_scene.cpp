@@ -1,0 +1,514 @@
+// Host scene construction for libptmi (CPU, once per scene).  Follows the reference's builders so that the trees —
+// and therefore traversal order, tie-breaking and the per-leaf t_enter estimates that enter triangle-test rounding —
+// are the reference's own:
+//   Triangle::new            src/tlas/tlas_bvh/blas/primitive.rs:31-54
+//   BLASNode::generate_blas  src/tlas/tlas_bvh/blas/blas_bvh.rs:62-136   (sorted sweep SAH, 64 bins)
+//   TLASNode::generate_tlas  src/tlas/tlas_bvh.rs:85-138                  (agglomerative clustering)
+//   LightSampler::new        src/scene/light_sampler.rs:41-61
+//   Camera::new              src/camera.rs:17-31
+#include "pt_scene.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace pt {
+
+namespace {
+
+const float kInf = __builtin_inff();
+
+HostBox box_empty() { return HostBox{bc3(kInf), bc3(-kInf)}; }                          // AABB::identity  boundingbox.rs:59-65
+HostBox box_join(const HostBox& a, const HostBox& b) { return HostBox{min3(a.mn, b.mn), max3(a.mx, b.mx)}; } // boundingbox.rs:134-139
+float box_area(const HostBox& b)                                                        // boundingbox.rs:90-95
+{
+    f3 v = b.mx - b.mn;
+    return 2.0f * dot3(v, f3{v.z, v.x, v.y});
+}
+int box_longest_axis(const HostBox& b)                                                  // boundingbox.rs:71-88
+{
+    f3 l = b.mx - b.mn;
+    float m = hmax3(l);
+    return l.x == m ? 0 : (l.y == m ? 1 : 2);
+}
+HostBox box_transform(const HostBox& b, const xf34& m)                                  // boundingbox.rs:51-57 (two corners only)
+{
+    f3 p = xf_point(m, b.mn), q = xf_point(m, b.mx);
+    return HostBox{min3(p, q), max3(p, q)};
+}
+float axis_of(const f3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+HostTriangle make_triangle(const float* p9, const float* n9)                            // primitive.rs:31-54
+{
+    HostTriangle t;
+    for (int k = 0; k < 3; ++k)
+    {
+        t.p[k] = f3{p9[k * 3], p9[k * 3 + 1], p9[k * 3 + 2]};
+        t.n[k] = f3{n9[k * 3], n9[k * 3 + 1], n9[k * 3 + 2]};
+    }
+    f3 ab = t.p[1] - t.p[0], ac = t.p[2] - t.p[0];
+    f3 n0 = cross3(ab, ac);
+    float d0 = dot3(n0, t.p[0]);
+    float scale = len_sq(n0);
+    f3 n1 = cross3(ac, n0) / scale;
+    float d1 = -dot3(n1, t.p[0]);
+    f3 n2 = cross3(n0, ab) / scale;
+    float d2 = -dot3(n2, t.p[0]);
+    t.n0 = f4{n0.x, n0.y, n0.z, d0};
+    t.n1 = f4{n1.x, n1.y, n1.z, d1};
+    t.n2 = f4{n2.x, n2.y, n2.z, d2};
+    return t;
+}
+HostBox triangle_box(const HostTriangle& t)                                             // primitive.rs:97-103
+{
+    return HostBox{min3(min3(t.p[0], t.p[1]), t.p[2]), max3(max3(t.p[0], t.p[1]), t.p[2])};
+}
+
+m33 inverse33(const m33& m) // glam Mat3A::inverse
+{
+    f3 r0 = cross3(m.c1, m.c2), r1 = cross3(m.c2, m.c0), r2 = cross3(m.c0, m.c1);
+    float inv_det = 1.0f / dot3(m.c2, r2);
+    f3 a = r0 * inv_det, b = r1 * inv_det, c = r2 * inv_det;
+    return m33{f3{a.x, b.x, c.x}, f3{a.y, b.y, c.y}, f3{a.z, b.z, c.z}};
+}
+xf34 inverse_affine(const xf34& a) // glam Affine3A::inverse
+{
+    m33 mi = inverse33(a.m);
+    return xf34{mi, -mul(mi, a.t)};
+}
+
+// SAH sweep builder over a contiguous span of (box, primitive) records.
+struct SweepItem { HostBox box; uint32_t prim; };
+struct SweepBuilder
+{
+    HostBlas& out;
+    std::vector<SweepItem>& items;
+    static constexpr size_t kBins = 64;             // DESIRED_BINS       blas_bvh.rs:13
+    static constexpr float kTraversal = 1.0f;       // TRAVERSAL_COST     blas_bvh.rs:15
+    static constexpr float kIntersect = 2.0f;       // INTERSECTION_COST  blas_bvh.rs:16
+
+    HostBox span_box(size_t lo, size_t hi) const                                        // blas_bvh.rs:28-33
+    {
+        HostBox b = box_empty();
+        for (size_t i = lo; i < hi; ++i) b = box_join(b, items[i].box);
+        return b;
+    }
+    uint32_t emit(const HostNode& n) { out.nodes.push_back(n); return (uint32_t)out.nodes.size() - 1; }
+
+    // returns (node id); depth_out = nodes on the longest path below and including this node
+    uint32_t run(size_t lo, size_t hi, int parent_axis, uint32_t* depth_out)
+    {
+        const size_t span = hi - lo;
+        if (span == 1)                                                                   // LeafSingle  blas_bvh.rs:67-75
+        {
+            uint32_t first = (uint32_t)out.prim_ids.size();
+            out.prim_ids.push_back(items[lo].prim);
+            *depth_out = 1;
+            return emit(HostNode{items[lo].box, NODE_TRIS, first, 1});
+        }
+        const HostBox bb = span_box(lo, hi);
+        const float bb_sa = box_area(bb);
+        const int axis = box_longest_axis(bb);
+        if (axis != parent_axis)                                                         // blas_bvh.rs:86-91 (glidesort: stable, total_cmp)
+        {
+            std::stable_sort(items.begin() + lo, items.begin() + hi, [axis](const SweepItem& l, const SweepItem& r) {
+                return total_order_key(axis_of(l.box.mn, axis)) < total_order_key(axis_of(r.box.mn, axis));
+            });
+        }
+        const size_t bin = std::max<size_t>(span / kBins, 1);
+        const size_t n_candidates = span / bin - 1;
+        size_t best_j = 0;
+        float best_cost = 0.0f;
+        for (size_t c = 0; c < n_candidates; ++c)                                        // blas_bvh.rs:96-110
+        {
+            const size_t j = (c + 1) * bin;
+            const float la = box_area(span_box(lo, lo + j)), ra = box_area(span_box(lo + j, hi));
+            const float cost = kTraversal + ((float)j * la + (float)(span - j) * ra) * kIntersect / bb_sa;
+            // min_by(total_cmp): first of equal minima wins
+            if (c == 0 || total_order_key(cost) < total_order_key(best_cost)) { best_cost = cost; best_j = j; }
+        }
+        const float leaf_cost = kIntersect * (float)span;                                // blas_bvh.rs:112
+        if (leaf_cost < best_cost)                                                       // Leaf{primitive_ids}  blas_bvh.rs:114-122
+        {
+            uint32_t first = (uint32_t)out.prim_ids.size();
+            for (size_t i = lo; i < hi; ++i) out.prim_ids.push_back(items[i].prim);
+            *depth_out = 1;
+            return emit(HostNode{bb, NODE_TRIS, first, (uint32_t)span});
+        }
+        uint32_t dl = 0, dr = 0;
+        const uint32_t left = run(lo, lo + best_j, axis, &dl);                           // blas_bvh.rs:125-133
+        const uint32_t right = run(lo + best_j, hi, axis, &dr);
+        *depth_out = 1 + std::max(dl, dr);
+        return emit(HostNode{bb, NODE_BRANCH, left, right});
+    }
+};
+
+uint32_t tree_depth(const std::vector<HostNode>& nodes, uint32_t root)
+{
+    // children always precede parents in arena order
+    std::vector<uint32_t> d(nodes.size(), 1);
+    for (size_t i = 0; i < nodes.size(); ++i)
+        if (nodes[i].kind == NODE_BRANCH) d[i] = 1 + std::max(d[nodes[i].a], d[nodes[i].b]);
+    return nodes.empty() ? 0 : d[root];
+}
+
+// ---- 4x4 helpers for the camera (column-major float[16]) ----
+void mat4_mul(const float* a, const float* b, float* out) // glam Mat4 * Mat4 (mul_vec4 per column)
+{
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+        {
+            float v = a[0 * 4 + r] * b[c * 4 + 0];
+            v = v + a[1 * 4 + r] * b[c * 4 + 1];
+            v = v + a[2 * 4 + r] * b[c * 4 + 2];
+            v = v + a[3 * 4 + r] * b[c * 4 + 3];
+            out[c * 4 + r] = v;
+        }
+}
+void mat4_inverse(const float* m, float* out) // glam Mat4::inverse (cofactor expansion)
+{
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+    const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+    const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+    const float m30 = m[12], m31 = m[13], m32 = m[14], m33_ = m[15];
+    const float c00 = m22 * m33_ - m32 * m23, c02 = m12 * m33_ - m32 * m13, c03 = m12 * m23 - m22 * m13;
+    const float c04 = m21 * m33_ - m31 * m23, c06 = m11 * m33_ - m31 * m13, c07 = m11 * m23 - m21 * m13;
+    const float c08 = m21 * m32 - m31 * m22, c10 = m11 * m32 - m31 * m12, c11 = m11 * m22 - m21 * m12;
+    const float c12 = m20 * m33_ - m30 * m23, c14 = m10 * m33_ - m30 * m13, c15 = m10 * m23 - m20 * m13;
+    const float c16 = m20 * m32 - m30 * m22, c18 = m10 * m32 - m30 * m12, c19 = m10 * m22 - m20 * m12;
+    const float c20 = m20 * m31 - m30 * m21, c22 = m10 * m31 - m30 * m11, c23 = m10 * m21 - m20 * m11;
+    const float fac0[4] = {c00, c00, c02, c03}, fac1[4] = {c04, c04, c06, c07}, fac2[4] = {c08, c08, c10, c11};
+    const float fac3[4] = {c12, c12, c14, c15}, fac4[4] = {c16, c16, c18, c19}, fac5[4] = {c20, c20, c22, c23};
+    const float v0[4] = {m10, m00, m00, m00}, v1[4] = {m11, m01, m01, m01}, v2[4] = {m12, m02, m02, m02}, v3[4] = {m13, m03, m03, m03};
+    const float sa[4] = {1.0f, -1.0f, 1.0f, -1.0f}, sb[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+    float inv[16];
+    for (int i = 0; i < 4; ++i)
+    {
+        inv[0 + i] = ((v1[i] * fac0[i] - v2[i] * fac1[i]) + v3[i] * fac2[i]) * sa[i];
+        inv[4 + i] = ((v0[i] * fac0[i] - v2[i] * fac3[i]) + v3[i] * fac4[i]) * sb[i];
+        inv[8 + i] = ((v0[i] * fac1[i] - v1[i] * fac3[i]) + v3[i] * fac5[i]) * sa[i];
+        inv[12 + i] = ((v0[i] * fac2[i] - v1[i] * fac4[i]) + v2[i] * fac5[i]) * sb[i];
+    }
+    const float d0 = m[0] * inv[0], d1 = m[1] * inv[4], d2 = m[2] * inv[8], d3 = m[3] * inv[12];
+    const float det = d0 + d1 + d2 + d3;
+    const float rcp = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * rcp;
+}
+f3 unit3_recip(f3 v) { float r = 1.0f / sqrtf(dot3(v, v)); return v * r; } // glam scalar Vec3::normalize
+
+} // namespace
+
+int HostScene::add_material(int kind, const float colour[3], float roughness, float ior, bool has_volume, const float vol_abs[3], float k,
+                            float c, float g)
+{
+    if (kind < 0 || kind > (int)MAT_DIELECTRIC) return -1;
+    DMaterial m;
+    std::memset(&m, 0, sizeof(m));
+    m.kind = (uint32_t)kind;
+    m.colour[0] = colour[0]; m.colour[1] = colour[1]; m.colour[2] = colour[2];
+    m.ior = ior;
+    if (kind == (int)MAT_GGX_METAL || kind == (int)MAT_GGX_DIELECTRIC) m.alpha = clamp_rs(sq(roughness), 0.0001f, 0.9999f); // material.rs:294,309
+    if (has_volume && (kind == (int)MAT_GGX_DIELECTRIC || kind == (int)MAT_DIELECTRIC))
+    {
+        m.has_volume = 1;
+        if (k != 0.0f) { m.vol_flags |= 1u; m.vol_abs[0] = vol_abs[0] * k; m.vol_abs[1] = vol_abs[1] * k; m.vol_abs[2] = vol_abs[2] * k; } // volume.rs:112,138
+        if (c != 0.0f) { m.vol_flags |= 2u; m.vol_c = c; m.vol_g = clamp_rs(g, -0.999f, 0.999f); }                                       // volume.rs:27,139
+    }
+    materials.push_back(m);
+    built = false;
+    return (int)materials.size() - 1;
+}
+
+int HostScene::add_model(const float* positions, const float* normals, uint32_t n_tris, int material, const float* affines, uint32_t n_inst)
+{
+    if (!positions || !normals || n_tris == 0 || material < 0 || material >= (int)materials.size() || (n_inst && !affines)) return -1;
+    HostModel m;
+    m.n_tris = n_tris;
+    m.material = material;
+    m.positions.assign(positions, positions + (size_t)n_tris * 9);
+    m.normals.assign(normals, normals + (size_t)n_tris * 9);
+    for (uint32_t i = 0; i < n_inst; ++i)
+    {
+        const float* r = affines + (size_t)i * 12;
+        xf34 x{m33{f3{r[0], r[4], r[8]}, f3{r[1], r[5], r[9]}, f3{r[2], r[6], r[10]}}, f3{r[3], r[7], r[11]}};
+        // model.rs:40-44: to_scale_rotation_translation().0 == Vec3::ONE or panic
+        const float det = dot3(x.m.c2, cross3(x.m.c0, x.m.c1));
+        const float sx = len3(x.m.c0) * signum_rs(det), sy = len3(x.m.c1), sz = len3(x.m.c2);
+        if (!(sx == 1.0f && sy == 1.0f && sz == 1.0f)) return -4;
+        m.matrices.push_back(x);
+    }
+    models.push_back(std::move(m));
+    built = false;
+    return (int)models.size() - 1;
+}
+
+void HostScene::build_blas(HostBlas& out, const HostModel& m)                           // BLAS::new  blas.rs:174-201
+{
+    out = HostBlas();
+    out.material = m.material;
+    out.tris.reserve(m.n_tris);
+    std::vector<SweepItem> items(m.n_tris);
+    for (uint32_t i = 0; i < m.n_tris; ++i)
+    {
+        out.tris.push_back(make_triangle(&m.positions[(size_t)i * 9], &m.normals[(size_t)i * 9]));
+        items[i] = SweepItem{triangle_box(out.tris.back()), i};
+    }
+    SweepBuilder sb{out, items};
+    out.root = sb.run(0, items.size(), 4, &out.depth);                                   // last_split_axis = 4  blas.rs:191
+}
+
+void HostScene::build_tlas(HostTlas& out, const std::vector<uint32_t>& model_ids)       // TLAS::new tlas.rs:24-53
+{
+    out = HostTlas();
+    out.models = model_ids;
+    std::vector<uint32_t> open; // the `nodes` worklist of tlas_bvh.rs:88
+    for (uint32_t a = 0; a < model_ids.size(); ++a)
+    {
+        const uint32_t mi = model_ids[a];
+        const HostBox root_box = blas[mi].nodes[blas[mi].root].box;
+        for (const xf34& mat : models[mi].matrices)
+        {
+            const uint32_t inst = (uint32_t)out.instances.size();
+            out.instances.push_back(HostInstance{a, mi, mat, inverse_affine(mat)});
+            out.nodes.push_back(HostNode{box_transform(root_box, mat), NODE_INSTANCE, inst, a});
+            open.push_back((uint32_t)out.nodes.size() - 1);
+        }
+    }
+    if (open.empty()) return;
+    auto best_partner = [&](size_t self) -> size_t {                                     // find_best_match  tlas_bvh.rs:56-83
+        float best = kInf;
+        size_t idx = SIZE_MAX;
+        for (size_t i = 0; i < open.size(); ++i)
+        {
+            if (i == self) continue;
+            const float sa = box_area(box_join(out.nodes[open[self]].box, out.nodes[open[i]].box));
+            if (sa < best) { best = sa; idx = i; }
+        }
+        return idx;
+    };
+    auto take = [&](size_t i) { uint32_t v = open[i]; open[i] = open.back(); open.pop_back(); return v; }; // Vec::swap_remove
+    size_t a = 0, b = open.size() > 1 ? best_partner(0) : SIZE_MAX;
+    while (open.size() > 1)                                                              // tlas_bvh.rs:110-136
+    {
+        const size_t c = best_partner(b);
+        if (a == c)
+        {
+            uint32_t n1, n2;
+            if (a > b) { n1 = take(a); n2 = take(b); } else { n1 = take(b); n2 = take(a); }
+            a = open.size();
+            out.nodes.push_back(HostNode{box_join(out.nodes[n1].box, out.nodes[n2].box), NODE_BRANCH, n1, n2});
+            open.push_back((uint32_t)out.nodes.size() - 1);
+            b = open.size() > 1 ? best_partner(a) : SIZE_MAX;
+        }
+        else { a = b; b = c; }
+    }
+    out.root = open[0];
+    out.depth = tree_depth(out.nodes, out.root);
+}
+
+void HostScene::build_lights()                                                          // tlas.rs:55-64, blas.rs:203-212, light_sampler.rs:41-61
+{
+    light_items.clear();
+    light_weight_sum = 0;
+    std::vector<float> weights;
+    for (uint32_t a = 0; a < lights.models.size(); ++a)
+    {
+        const HostBlas& bl = blas[lights.models[a]];
+        const DMaterial& mat = materials[bl.material];
+        const float emitted_len = len3(f3{mat.colour[0], mat.colour[1], mat.colour[2]});
+        for (uint32_t p = 0; p < bl.tris.size(); ++p)
+        {
+            const float area = 0.5f * len3(f3{bl.tris[p].n0.x, bl.tris[p].n0.y, bl.tris[p].n0.z}); // primitive.rs:94
+            weights.push_back(area * emitted_len);
+            light_items.push_back(HostLight{a, p, 0, 0});
+        }
+    }
+    float sum = 0.0f;
+    for (float w : weights) sum = sum + w;
+    light_weight_sum = sum;
+    float running = 0.0f;
+    for (size_t i = 0; i < light_items.size(); ++i)
+    {
+        light_items[i].pdf = weights[i] / sum;
+        running += light_items[i].pdf;
+        light_items[i].cdf = running;
+    }
+}
+
+int HostScene::build(std::string* err)                                                  // Scene::new  scene.rs:21-35
+{
+    if (models.empty()) { if (err) *err = "no models"; return -3; }
+    blas.resize(models.size());
+    for (size_t i = 0; i < models.size(); ++i) build_blas(blas[i], models[i]);
+    std::vector<uint32_t> all(models.size()), emissive;
+    std::iota(all.begin(), all.end(), 0u);
+    for (uint32_t i = 0; i < models.size(); ++i)
+        if (materials[models[i].material].kind == MAT_EMISSIVE) emissive.push_back(i);
+    build_tlas(world, all);
+    build_tlas(lights, emissive);
+    build_lights();
+    int r = flatten(err);
+    built = (r == 0);
+    return r;
+}
+
+int HostScene::flatten(std::string* err)
+{
+    FlatScene f;
+    f.materials = materials;
+    // absolute node layout: world TLAS | lights TLAS | BLAS 0 | BLAS 1 | ...
+    const uint32_t world_base = 0;
+    const uint32_t lights_base = (uint32_t)world.nodes.size();
+    std::vector<uint32_t> blas_base(blas.size());
+    uint32_t cursor = lights_base + (uint32_t)lights.nodes.size();
+    uint32_t tri_cursor = 0;
+    f.tri_base.resize(blas.size());
+    for (size_t i = 0; i < blas.size(); ++i)
+    {
+        blas_base[i] = cursor;
+        cursor += (uint32_t)blas[i].nodes.size();
+        f.tri_base[i] = tri_cursor;
+        tri_cursor += (uint32_t)blas[i].prim_ids.size();
+    }
+    if (cursor > NODE_PAYLOAD_MASK || tri_cursor > NODE_PAYLOAD_MASK) { if (err) *err = "scene too large for 30-bit node payloads"; return -5; }
+    f.nodes.resize(cursor);
+    f.inst_base = {0u, (uint32_t)world.instances.size()};
+
+    auto put_box = [](DNode& d, const HostBox& b) {
+        d.mn[0] = b.mn.x; d.mn[1] = b.mn.y; d.mn[2] = b.mn.z;
+        d.mx[0] = b.mx.x; d.mx[1] = b.mx.y; d.mx[2] = b.mx.z;
+    };
+    auto put_tlas = [&](const HostTlas& t, uint32_t base, uint32_t inst_base) {
+        for (size_t i = 0; i < t.nodes.size(); ++i)
+        {
+            DNode& d = f.nodes[base + i];
+            put_box(d, t.nodes[i].box);
+            if (t.nodes[i].kind == NODE_BRANCH) { d.a = base + t.nodes[i].a; d.b = (NODE_BRANCH << NODE_KIND_SHIFT) | (base + t.nodes[i].b); }
+            else { d.a = inst_base + t.nodes[i].a; d.b = (NODE_INSTANCE << NODE_KIND_SHIFT); }
+        }
+    };
+    put_tlas(world, world_base, f.inst_base[0]);
+    put_tlas(lights, lights_base, f.inst_base[1]);
+    f.world_root = world.root == MISS_ID ? MISS_ID : world_base + world.root;
+    f.lights_root = lights.root == MISS_ID ? MISS_ID : lights_base + lights.root;
+
+    uint32_t max_blas_depth = 0;
+    for (size_t i = 0; i < blas.size(); ++i)
+    {
+        const HostBlas& bl = blas[i];
+        max_blas_depth = std::max(max_blas_depth, bl.depth);
+        for (size_t n = 0; n < bl.nodes.size(); ++n)
+        {
+            DNode& d = f.nodes[blas_base[i] + n];
+            put_box(d, bl.nodes[n].box);
+            if (bl.nodes[n].kind == NODE_BRANCH) { d.a = blas_base[i] + bl.nodes[n].a; d.b = (NODE_BRANCH << NODE_KIND_SHIFT) | (blas_base[i] + bl.nodes[n].b); }
+            else { d.a = f.tri_base[i] + bl.nodes[n].a; d.b = (NODE_TRIS << NODE_KIND_SHIFT) | bl.nodes[n].b; }
+        }
+        for (uint32_t id : bl.prim_ids) // triangles stored in leaf order
+        {
+            const HostTriangle& t = bl.tris[id];
+            f.tri_isect.push_back(DTriIsect{t.n0, t.n1, t.n2});
+            f.tri_shade.push_back(DTriVerts{f4{t.n[0].x, t.n[0].y, t.n[0].z, 0}, f4{t.n[1].x, t.n[1].y, t.n[1].z, 0}, f4{t.n[2].x, t.n[2].y, t.n[2].z, 0}});
+            f.tri_pos.push_back(DTriVerts{f4{t.p[0].x, t.p[0].y, t.p[0].z, 0}, f4{t.p[1].x, t.p[1].y, t.p[1].z, 0}, f4{t.p[2].x, t.p[2].y, t.p[2].z, 0}});
+            f.tri_orig.push_back(id);
+        }
+    }
+    auto put_instances = [&](const HostTlas& t) {
+        for (const HostInstance& hi : t.instances)
+        {
+            DInstance d;
+            std::memset(&d, 0, sizeof(d));
+            const xf34* src[2] = {&hi.inv, &hi.fwd};
+            float* dst[2] = {d.inv, d.fwd};
+            for (int k = 0; k < 2; ++k)
+            {
+                const xf34& x = *src[k];
+                const float rows[12] = {x.m.c0.x, x.m.c1.x, x.m.c2.x, x.t.x, x.m.c0.y, x.m.c1.y, x.m.c2.y, x.t.y, x.m.c0.z, x.m.c1.z, x.m.c2.z, x.t.z};
+                std::memcpy(dst[k], rows, sizeof(rows));
+            }
+            d.root = blas_base[hi.model] + blas[hi.model].root;
+            d.blas = hi.blas;
+            d.material = (uint32_t)blas[hi.model].material;
+            switch (materials[d.material].kind)
+            {
+            case MAT_LAMBERTIAN: d.qclass = Q_LAMBERT; break;
+            case MAT_SPECULAR: d.qclass = Q_SPECULAR; break;
+            case MAT_DIELECTRIC: d.qclass = Q_DIELECTRIC; break;
+            case MAT_GGX_METAL:
+            case MAT_GGX_DIELECTRIC: d.qclass = Q_GGX; break;
+            default: d.qclass = Q_TERMINAL; break;
+            }
+            f.instances.push_back(d);
+        }
+    };
+    put_instances(world);
+    put_instances(lights);
+
+    // leaf-order position of every load-order primitive, per model
+    std::vector<std::vector<uint32_t>> where(blas.size());
+    for (size_t i = 0; i < blas.size(); ++i)
+    {
+        where[i].assign(blas[i].tris.size(), 0);
+        for (size_t k = 0; k < blas[i].prim_ids.size(); ++k) where[i][blas[i].prim_ids[k]] = f.tri_base[i] + (uint32_t)k;
+    }
+    for (const HostLight& l : light_items)
+    {
+        const uint32_t mi = lights.models[l.blas];
+        f.lights.push_back(DLight{where[mi][l.prim], (uint32_t)blas[mi].material, l.pdf, l.cdf});
+    }
+    f.light_weight_sum = light_weight_sum;
+
+    uint32_t pb = 1;
+    while ((1ull << pb) < (uint64_t)std::max<uint32_t>(tri_cursor, 2)) ++pb;
+    f.prim_bits = pb;
+    if ((uint64_t)f.instances.size() >= (1ull << (32 - pb)) - 1) { if (err) *err = "instance x triangle id does not fit 32 bits"; return -5; }
+    // near-first DFS keeps at most one pending sibling per level: TLAS levels + BLAS levels (+1 slack, rounded to even)
+    const uint32_t tlas_depth = std::max(world.depth, lights.depth);
+    f.stack_entries = ((tlas_depth + max_blas_depth + 1 + 1) / 2) * 2;
+    flat = std::move(f);
+    return 0;
+}
+
+void HostScene::set_camera(const float eye_[3], const float target_[3], float fov_deg, float aspect)     // Camera::new  camera.rs:17-31
+{
+    const f3 eye{eye_[0], eye_[1], eye_[2]}, target{target_[0], target_[1], target_[2]};
+    // Affine3A::look_at_rh(eye, center, Y) == look_to_lh(eye, -(center - eye), Y)
+    const f3 up{0.0f, 1.0f, 0.0f};
+    const f3 fwd = unit3_recip(-(target - eye));
+    const f3 side = unit3_recip(cross3(up, fwd));
+    const f3 upv = cross3(fwd, side);
+    const xf34 view{m33{f3{side.x, upv.x, fwd.x}, f3{side.y, upv.y, fwd.y}, f3{side.z, upv.z, fwd.z}},
+                    f3{-dot3(side, eye), -dot3(upv, eye), -dot3(fwd, eye)}};
+    camera.matrix = inverse_affine(view);
+    // Mat4::perspective_infinite_rh(fov.to_radians(), aspect, 1.0)
+    const float fov = fov_deg * (3.14159265358979323846f / 180.0f);
+    const float fl = 1.0f / tan_det(0.5f * fov);
+    const float proj[16] = {fl / aspect, 0, 0, 0, 0, fl, 0, 0, 0, 0, -1.0f, -1.0f, 0, 0, -1.0f, 0};
+    mat4_inverse(proj, camera.inv_proj);
+    const xf34& m = camera.matrix;
+    const float m4[16] = {m.m.c0.x, m.m.c0.y, m.m.c0.z, 0, m.m.c1.x, m.m.c1.y, m.m.c1.z, 0, m.m.c2.x, m.m.c2.y, m.m.c2.z, 0, m.t.x, m.t.y, m.t.z, 1.0f};
+    mat4_mul(m4, camera.inv_proj, camera.ray_matrix);
+    camera.set = true;
+}
+
+void HostScene::create_ray(float s, float t, float o[3], float d[3]) const                // Camera::create_ray  camera.rs:94-105
+{
+    const float* M = camera.ray_matrix;
+    const float nx = s * 2.0f - 1.0f, ny = t * 2.0f - 1.0f, nz = 0.0f;
+    float r[4];
+    for (int i = 0; i < 4; ++i) // Mat4::project_point3
+    {
+        float v = M[i] * nx;
+        v = M[4 + i] * ny + v;
+        v = M[8 + i] * nz + v;
+        v = M[12 + i] + v;
+        r[i] = v;
+    }
+    const float rw = 1.0f / r[3];
+    const f3 point{r[0] * rw, r[1] * rw, r[2] * rw};
+    const f3 dir = unit3(point - camera.matrix.t);
+    o[0] = camera.matrix.t.x; o[1] = camera.matrix.t.y; o[2] = camera.matrix.t.z;
+    d[0] = dir.x; d[1] = dir.y; d[2] = dir.z;
+}
+
+} // namespace pt

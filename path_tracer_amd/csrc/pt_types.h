@@ -1,0 +1,160 @@
+// Flattened scene + wavefront state layouts shared by the host builder and the gfx950 kernels.
+//
+// HBM layout (all arrays 16-byte aligned, read through 16-byte vector loads):
+//   nodes      : 32 B  { min.xyz, a | max.xyz, b }   TLAS(world) | TLAS(lights) | BLAS 0 | BLAS 1 ...   absolute indices
+//                b>>30 = kind: 0 branch (a = left, b&mask = right), 1 triangle leaf (a = first triangle, b&mask = count),
+//                             2 instance leaf (a = instance record)
+//   tri_isect  : 48 B  Havel-Herout planes n0|d0, n1|d1, n2|d2 (primitive.rs:20-26), BLAS-leaf order
+//   tri_shade  : 48 B  vertex normals  (3 x float4, w unused)
+//   tri_pos    : 48 B  vertex positions (3 x float4, w unused)  - only light sampling reads it
+//   instances  : 112 B inverse 3x4 | forward 3x4 | blas root, blas id, material, first_id
+//   materials  : 48 B
+//   lights     : 16 B  { triangle, material, pdf, cdf }
+// Traversal touches nodes + tri_isect + instances only ("scene blob"); when that fits it is staged in LDS.
+#pragma once
+#include <stdint.h>
+#include "pt_math.h"
+
+namespace pt {
+
+enum : uint32_t
+{
+    NODE_BRANCH = 0u,
+    NODE_TRIS = 1u,
+    NODE_INSTANCE = 2u,
+    NODE_KIND_SHIFT = 30u,
+    NODE_PAYLOAD_MASK = 0x3fffffffu,
+    MISS_ID = 0xffffffffu
+};
+
+struct alignas(16) DNode
+{
+    float mn[3];
+    uint32_t a;
+    float mx[3];
+    uint32_t b;
+};
+static_assert(sizeof(DNode) == 32, "node is two 16-byte words");
+
+struct alignas(16) DTriIsect { f4 n0, n1, n2; };
+static_assert(sizeof(DTriIsect) == 48, "");
+struct alignas(16) DTriVerts { f4 a, b, c; };
+
+struct alignas(16) DInstance
+{
+    float inv[12];  // rows of the inverse instance matrix (ray -> object space)       tlas_bvh.rs:41-43
+    float fwd[12];  // rows of the instance matrix (object normal -> world)            tlas.rs:105
+    uint32_t root;  // absolute node index of the BLAS root
+    uint32_t blas;  // BLAS (= model) index in its TLAS arena; world: first_id source   integrator.rs:184
+    uint32_t material;
+    uint32_t qclass; // shade-queue class of the material (Q_*)
+};
+static_assert(sizeof(DInstance) == 112, "");
+
+enum : uint32_t { MAT_LAMBERTIAN = 0, MAT_EMISSIVE = 1, MAT_SPECULAR = 2, MAT_GGX_METAL = 3, MAT_GGX_DIELECTRIC = 4, MAT_DIELECTRIC = 5 };
+
+struct alignas(16) DMaterial
+{
+    float colour[3];
+    uint32_t kind;
+    float alpha;       // GGX a
+    float ior;
+    uint32_t has_volume;
+    uint32_t vol_flags; // bit0 absorption, bit1 scatter
+    float vol_abs[3];   // absorption * k
+    float vol_c;
+    float vol_g;
+    float pad[3];
+};
+static_assert(sizeof(DMaterial) == 64, "");
+
+struct alignas(16) DLight
+{
+    uint32_t tri;      // absolute triangle index (leaf order)
+    uint32_t material;
+    float pdf;         // weight / sum                                               light_sampler.rs:47
+    float cdf;         // running sum of pdf                                         light_sampler.rs:50-56
+};
+
+// shade-queue classes (one shading kernel each)
+enum : uint32_t { Q_TERMINAL = 0, Q_LAMBERT = 1, Q_SPECULAR = 2, Q_DIELECTRIC = 3, Q_GGX = 4, Q_COUNT = 5 };
+enum : uint32_t { ENTRY_DEAD = 0x80000000u };
+
+// per-bounce counter row (zeroed once per batch)
+struct Counters
+{
+    uint32_t n_closest;      // rays in the world closest-hit queue of this bounce
+    uint32_t head_closest;   // persistent-thread fetch cursor
+    uint32_t n_shadow;       // explicit-light shadow rays produced by this bounce's shading
+    uint32_t head_shadow;
+    uint32_t n_lchain;       // BSDF-sampled NEE rays (lights TLAS closest hit, then world any hit)
+    uint32_t head_lchain;
+    uint32_t head_lchain_any;
+    uint32_t n_lchain_hit;   // of those, how many hit a light (= any-hit casts of integrator.rs:103)
+    uint32_t n_shade[Q_COUNT];
+    uint32_t pad[3];
+};
+static_assert(sizeof(Counters) == 64, "");
+
+struct SceneView
+{
+    const DNode* nodes;
+    const DTriIsect* tri_isect;
+    const DTriVerts* tri_shade;
+    const DTriVerts* tri_pos;
+    const uint32_t* tri_orig;     // leaf-order index -> (blas-local) load-order primitive id
+    const DInstance* instances;
+    const DMaterial* materials;
+    const DLight* lights;
+    uint32_t n_nodes, n_tris, n_instances, n_materials, n_lights;
+    uint32_t world_root, lights_root; // absolute node indices (MISS_ID: empty TLAS)
+    uint32_t prim_bits;               // hit id = (instance << prim_bits) | triangle
+    float light_weight_sum;           // LightSampler::max                         light_sampler.rs:43
+    uint32_t blob_bytes;              // nodes + tri_isect + instances, multiple of 16
+    uint32_t stack_entries;           // per-lane traversal stack capacity
+};
+
+struct CameraView
+{
+    float ray_matrix[16]; // (matrix * inv_projection), column-major                camera.rs:98
+    float eye[3];         // matrix.translation
+    float pad;
+};
+
+struct RenderParams
+{
+    uint32_t width, height;
+    uint32_t local_rows, local_pixels;
+    uint32_t rank, world_size, strip_rows;
+    uint32_t first_sample;   // global index of batch-local sample 0
+    uint32_t batch_samples;
+    uint32_t n_paths;        // local_pixels * batch_samples
+    uint32_t max_bounces, n_sobol, enable_nee;
+    uint32_t pad;
+    uint64_t seed;
+};
+
+// wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel), SoA of 16-byte words
+struct PathState
+{
+    f4* pw;        // path_weight.xyz | draws consumed (bits)
+    f4* acc;       // accumulated.xyz | flags (bits): [15:0] bounce, bit16 last_delta, bit17 nee pending, bit18 bsdf ray cast
+    f4* nee_e;     // explicit-light candidate contribution (integrator.rs:69-70) | unused
+    f4* nee_pw;    // path_weight at NEE time | bsdf pdf of the BSDF-sampled direction
+    f4* nee_b;     // bsdf rgb of the BSDF-sampled direction | weakening
+    f4* lhit;      // lights-TLAS closest hit of the BSDF-sampled ray: t,u,v | id
+    uint32_t* occl_e; // 1 = explicit shadow ray blocked
+    uint32_t* occl_b; // 1 = BSDF-sampled ray blocked before the light
+    f4* first_pos; // first-hit xyz | t        (main.rs:205)
+    uint32_t* first_id;
+};
+enum : uint32_t { FLAG_BOUNCE_MASK = 0xffffu, FLAG_LAST_DELTA = 1u << 16, FLAG_NEE_PENDING = 1u << 17, FLAG_BSDF_CAST = 1u << 18 };
+
+// dense ray queue: A = origin.xyz | t_max, B = direction.xyz | path id (bits)
+struct RayQueue
+{
+    f4* a;
+    f4* b;
+};
+
+} // namespace pt

@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of the pixel loop: one process per GPU, rows dealt to ranks in strips, no data-path collective
+while rendering (pixels are independent, src/main.rs:181-207), one gather of the final framebuffer to rank 0
+(torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def rows_of_rank(height: int, rank: int, world_size: int, strip_rows: int) -> np.ndarray:
+    """Global rows rendered by `rank` (same rule as libptmi's compute_rows / global_row)."""
+    y = np.arange(height, dtype=np.int64)
+    return y[(y // strip_rows) % world_size == rank]
+
+
+def max_rows(height: int, world_size: int, strip_rows: int) -> int:
+    return max(len(rows_of_rank(height, r, world_size, strip_rows)) for r in range(world_size))
+
+
+class _DevPtr:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can view libptmi's framebuffer in place."""
+
+    def __init__(self, ptr: int, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_framebuffer(ptr: int, rows: int, width: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevPtr(ptr, (rows, width, 4)), device=device)
+
+
+def gather_framebuffer(local: torch.Tensor, height: int, width: int, rank: int, world_size: int, strip_rows: int, dst: int = 0):
+    """Gather the per-rank (local_rows, width, 4) accumulation buffers on `dst` and de-interleave into (height, width, 4).
+    Returns the full framebuffer on dst and None elsewhere.  Equal-size chunks: ranks with fewer rows pad."""
+    if world_size == 1:
+        return local
+    pad_rows = max_rows(height, world_size, strip_rows)
+    send = local
+    if local.shape[0] != pad_rows:
+        send = torch.zeros((pad_rows, width, 4), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    send = send.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(send) for _ in range(world_size)]
+        dist.gather(send, parts, dst=dst)
+        full = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
+        for r in range(world_size):
+            rows = torch.from_numpy(rows_of_rank(height, r, world_size, strip_rows)).to(local.device)
+            full[rows] = parts[r][: len(rows)]
+        return full
+    dist.gather(send, None, dst=dst)
+    return None

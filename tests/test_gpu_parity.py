@@ -1,0 +1,239 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs and against
+the committed golden fixtures.  Bar: bit-exact (float results compared as u32 bit patterns)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from path_tracer_amd import api
+    api.lib()
+    return api
+
+
+@pytest.fixture(scope="module")
+def r256(api, cornell256):
+    return api.Renderer(cornell256, 256, 256, max_bounces=4)
+
+
+def test_device_arithmetic_matches_host(api, oracle_mod, cornell64):
+    """division, sqrt, the deterministic sin/cos/exp/ln/hypot and the WyRand stream are the same function on both sides"""
+    r = api.Renderer(cornell64, 64, 64)
+    rng = np.random.default_rng(0)
+    n = 1 << 16
+    x = rng.uniform(0, 2 * np.pi, n).astype(np.float32)
+    gs, gc = r.math_batch(0, x)
+    cs, cc = oracle_mod.math_batch(0, x)
+    assert_bit_equal(gs, cs, "sin"); assert_bit_equal(gc, cc, "cos")
+    x = np.concatenate([rng.uniform(-100, 100, n - 4), [0, -0.0, 88.8, -104]]).astype(np.float32)
+    assert_bit_equal(r.math_batch(1, x)[0], oracle_mod.math_batch(1, x)[0], "exp")
+    x = np.concatenate([np.exp(rng.uniform(-80, 80, n - 4)), [0, 1, 1e-42, 3e38]]).astype(np.float32)
+    assert_bit_equal(r.math_batch(2, x)[0], oracle_mod.math_batch(2, x)[0], "ln")
+    a = (rng.normal(size=n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    b = (rng.normal(size=n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    a[:4] = [0, 1, -1, 3]; b[:4] = [0, 0, 3, -0.0]
+    assert_bit_equal(r.math_batch(3, a, b)[0], oracle_mod.math_batch(3, a, b)[0], "hypot")
+    with np.errstate(all="ignore"):
+        assert_bit_equal(r.math_batch(4, a, b)[0], oracle_mod.math_batch(4, a, b)[0], "divide")
+        assert_bit_equal(r.math_batch(5, np.abs(a))[0], oracle_mod.math_batch(5, np.abs(a))[0], "sqrt")
+    # denormal operands must not be flushed
+    d = (rng.uniform(1, 100, n) * 1e-41).astype(np.float32)
+    assert_bit_equal(r.math_batch(4, d, np.full(n, 3.0, np.float32))[0], (d / np.float32(3.0)).astype(np.float32), "denormal divide")
+    # RNG: first u32 and second f32 draw of stream (pixel, sample)
+    px = rng.integers(0, 1 << 31, n).astype(np.uint32); sm = rng.integers(0, 4096, n).astype(np.uint32)
+    g0, g1 = r.math_batch(7, px.view(np.float32), sm.view(np.float32))
+    L = oracle_mod.lib()
+    for i in range(0, n, 997):
+        s0 = L.pto_stream_state0(api.DEFAULT_SEED, int(px[i]), int(sm[i]))
+        assert int(g0[i:i + 1].view(np.uint32)[0]) == L.pto_wyrand(s0, 0) & 0xFFFFFFFF
+        assert g1[i] == np.float32(np.float32(L.pto_wyrand(s0, 1) & 0xFFFFFFFF) / np.float32(4294967296.0))
+
+
+def test_device_sobol_matches_known_answers(api, oracle_mod, cornell64):
+    r = api.Renderer(cornell64, 64, 64)
+    kat = [(0, 0, 0xA30AE09A, 0x231C175E), (1, 0, 0x19984A78, 0x9ECD1C95), (0, 1, 0x6B17BD49, 0x0EE62FF7),
+           (5, 0xDEADBEEF, 0x646F0B04, 0x9E5AF2A8), (255, 12345, 0xE2891023, 0x053CCA92)]
+    out = r.ss_sobol(512, [k[0] for k in kat], [k[1] for k in kat])
+    for o, k in zip(out, kat):
+        assert o[0] == np.float32(np.float32(k[2]) / np.float32(4294967296.0)) and o[1] == np.float32(np.float32(k[3]) / np.float32(4294967296.0))
+    rng = np.random.default_rng(1)
+    for n_points in (512, 2, 100000, 1 << 31):
+        idx = rng.integers(0, 1 << 32, 4096, dtype=np.uint64).astype(np.uint32); seed = rng.integers(0, 1 << 32, 4096, dtype=np.uint64).astype(np.uint32)
+        g = r.ss_sobol(n_points, idx, seed)
+        c = np.stack([oracle_mod.ss_sobol(n_points, int(i), int(s)) for i, s in zip(idx[:512], seed[:512])])
+        assert_bit_equal(g[:512], c, f"ss_sobol N={n_points}")
+
+
+def test_trace_closest_golden_rays(r256):
+    g = np.load(os.path.join(GOLD, "cornell_c1.npz"))
+    h = r256.trace_closest(g["ray_o"], g["ray_d"])
+    for k in ("t", "u", "v", "inst", "prim"):
+        assert_bit_equal(h[k], g["hit_" + k], f"closest.{k}")
+
+
+def test_trace_any_golden_rays(r256):
+    g = np.load(os.path.join(GOLD, "cornell_c1.npz"))
+    assert np.array_equal(r256.trace_any(g["ray_o"], g["ray_d"], g["any_tmax"]), g["any_hit"])
+
+
+@pytest.mark.parametrize("scene_name,n", [("cornell_box", 20000), ("cornell_mixed", 5000)])
+def test_trace_matches_oracle_on_random_rays(api, oracle_mod, scene_name, n):
+    from path_tracer_amd import scenes
+    sc = getattr(scenes, scene_name)(64, 64)
+    r = api.Renderer(sc, 64, 64)
+    o = oracle_mod.Oracle(sc)
+    rng = np.random.default_rng(3)
+    O = rng.uniform(-270, 270, (n, 3)).astype(np.float32)
+    O[:, 1] += 50
+    D = rng.normal(size=(n, 3))
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    # axis-aligned directions (zero components -> infinite inverse direction -> NaN slabs) and degenerate cases
+    D[:300] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1.0, 1.0], (300, 1)).astype(np.float32)
+    O[300:400] = np.round(O[300:400] / 139) * 139           # origins on box planes
+    D[400:420, 2] = -0.0
+    D[400:420] /= np.linalg.norm(D[400:420], axis=1, keepdims=True)
+    for which in (0, 1):
+        g = r.trace_closest(O, D, which=which)
+        c = o.trace_closest(O, D, which=which)
+        for k in ("inst", "prim", "t", "u", "v"):
+            assert_bit_equal(g[k], c[k], f"{scene_name} tlas{which} closest.{k}")
+    tm = rng.uniform(0, 800, n).astype(np.float32)
+    tm[:50] = np.nan
+    tm[50:100] = np.inf
+    tm[100:120] = 0.0
+    assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))
+    assert np.array_equal(r.trace_any(O, D, tm, which=1), o.trace_any(O, D, tm, which=1))
+    # closest hit with a finite initial t_max (integrate always passes INFINITY, the hook accepts any)
+    g = r.trace_closest(O, D, tm)
+    c = o.trace_closest(O, D, tm)
+    for k in ("inst", "prim", "t"):
+        assert_bit_equal(g[k], c[k], f"closest with t_max .{k}")
+
+
+def test_materials_match_oracle(api, oracle_mod):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Dielectric, GGX, Lambertian, Model, SceneDesc, Specular, Emissive
+    sc = scenes.cornell_box(32, 32)
+    kinds = [Lambertian.new((0.7, 0.6, 0.5)), Specular.new((0.9, 0.9, 0.8)), GGX.new_metal((0.1, 0.1, 0.45), 0.4),
+             GGX.new_dielectric((0.95, 0.95, 0.95), 0.2, 1.5, None), GGX.new_dielectric((1, 1, 1), 0.0, 1.5, None), Dielectric.new((0.95, 0.95, 0.95), 1.5, None),
+             GGX.new_metal((0.9, 0.5, 0.2), 1.0)]
+    tri = sc.models[0]
+    models = [Model.new(tri.positions, tri.normals, Emissive.new((1, 1, 1)))] + [Model.new(tri.positions + np.float32(10 * (i + 1)), tri.normals, m) for i, m in enumerate(kinds)]
+    scene = SceneDesc.new(models, sc.camera)
+    r = api.Renderer(scene, 32, 32)
+    o = oracle_mod.Oracle(scene)
+    mats = scene.materials()
+    rng = np.random.default_rng(11)
+    n = 3000
+    nrm = rng.normal(size=(n, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    inc = rng.normal(size=(n, 3)); inc = (inc / np.linalg.norm(inc, axis=1, keepdims=True)).astype(np.float32)
+    flip = (inc * nrm).sum(1) > 0          # incoming direction points into the surface: dot(incoming, normal) < 0 after face-forwarding
+    inc[flip] = -inc[flip]
+    inc[:50] = -nrm[:50]                   # normal incidence
+    nrm[50:60] = [0, 0, 1]; nrm[60:70] = [0, 0, -1]
+    front = rng.integers(0, 2, n).astype(np.uint8)
+    px = rng.integers(0, 1 << 20, n).astype(np.uint32); sm = rng.integers(0, 256, n).astype(np.uint32)
+    for m in kinds:
+        mi = mats.index(m)
+        g = r.material_eval(mi, inc, nrm, front, px, sm, 3)
+        c = np.stack([o.material_eval(mi, inc[i], nrm[i], front[i], int(px[i]), int(sm[i]), 3) for i in range(n)])
+        assert_bit_equal(g, c, f"material kind {m.kind} roughness {m.roughness}")
+
+
+def test_per_sample_radiance_bit_exact_vs_golden(api):
+    from path_tracer_amd import scenes
+    g = np.load(os.path.join(GOLD, "samples_small.npz"))
+    r = api.Renderer(scenes.cornell_box(64, 64), 64, 64, max_bounces=8)
+    assert_bit_equal(r.render_samples(0, 4), g["cornell64"], "cornell 64x64 per-sample radiance")
+    r = api.Renderer(scenes.cornell_mixed(48, 48), 48, 48, max_bounces=8)
+    assert_bit_equal(r.render_samples(0, 4), g["mixed48"], "mixed-material 48x48 per-sample radiance")
+
+
+def test_config1_image_bit_exact(api, oracle_mod, cornell256):
+    """BASELINE.json configs[0]: Cornell 256x256, 16 spp, depth 4 — checksum + crop from the fixture, then the live oracle."""
+    g = np.load(os.path.join(GOLD, "cornell_c1.npz"))
+    r = api.Renderer(cornell256, 256, 256, max_bounces=4, flags=api.FLAG_TIMING)
+    acc, pos, idb = r.render(0, 16)
+    assert hashlib.sha256(acc.tobytes()).digest() == g["sha256"].tobytes()
+    assert_bit_equal(acc[96:160, 96:160], g["crop"], "C1 crop")
+    assert_bit_equal(pos[96:160, 96:160], g["pos_crop"], "C1 first-hit position")
+    assert np.array_equal(idb[96:160, 96:160], g["id_crop"])
+    st = r.stats()
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest, st.paths) == tuple(int(x) for x in g["counters"][[0, 1, 2, 5]])
+    o = oracle_mod.Oracle(cornell256)
+    oacc, opos, oid, _ = o.render(256, 256, 16, max_bounces=4)
+    assert_bit_equal(acc, oacc, "C1 image"); assert_bit_equal(pos, opos, "C1 position"); assert np.array_equal(idb, oid)
+
+
+@pytest.mark.parametrize("kw", [dict(max_bounces=0), dict(max_bounces=1), dict(max_bounces=12), dict(enable_nee=False, max_bounces=6),
+                                dict(max_bounces=40), dict(n_sobol=2, max_bounces=3), dict(seed=12345, max_bounces=5)])
+def test_integrator_variants_bit_exact(api, oracle_mod, kw):
+    from path_tracer_amd import scenes
+    sc = scenes.cornell_mixed(40, 24)
+    r = api.Renderer(sc, 40, 24, **kw)
+    o = oracle_mod.Oracle(sc)
+    okw = dict(kw)
+    if "enable_nee" in okw:
+        okw["enable_nee"] = int(okw["enable_nee"])
+    assert_bit_equal(r.render_samples(3, 3), o.render_samples(40, 24, 3, first_sample=3, **okw), str(kw))
+
+
+def test_batching_resume_and_sharding_do_not_change_the_image(api, oracle_mod):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.dist import rows_of_rank
+    sc = scenes.cornell_box(48, 30)
+    ref = api.Renderer(sc, 48, 30, max_bounces=5).render(0, 6)
+    small = api.Renderer(sc, 48, 30, max_bounces=5, batch_spp=1)
+    a1 = small.render(0, 6)
+    for x, y, w in zip(ref, a1, ("acc", "pos", "id")):
+        assert_bit_equal(x, y, f"batch_spp=1 {w}")
+    res = api.Renderer(sc, 48, 30, max_bounces=5, batch_spp=4)
+    res.render(0, 2)
+    idb = np.zeros((30, 48), np.uint32)
+    res.reset_accumulation()
+    res.render(0, 4, ident=idb)
+    a2 = res.render(4, 2, ident=idb)
+    assert_bit_equal(ref[0], a2[0], "resumed accumulation"); assert np.array_equal(ref[2], a2[2])
+    # three ranks' row strips assembled == single-GPU frame (counter RNG is keyed by the global pixel)
+    full = np.zeros_like(ref[0])
+    for rank in range(3):
+        rr = api.Renderer(sc, 48, 30, max_bounces=5, rank=rank, world_size=3, strip_rows=4)
+        full[rows_of_rank(30, rank, 3, 4)] = rr.render(0, 6)[0]
+    assert_bit_equal(ref[0], full, "row-sharded render")
+    o = oracle_mod.Oracle(sc)
+    assert_bit_equal(ref[0], o.render(48, 30, 6, max_bounces=5)[0], "vs oracle")
+
+
+def test_empty_and_edge_inputs(api, cornell64):
+    r = api.Renderer(cornell64, 64, 64)
+    z = np.zeros((0, 3), np.float32)
+    assert r.trace_closest(z, z)["t"].shape == (0,)
+    acc, _, _ = r.render(0, 0)
+    assert (acc == 0).all()
+    one = api.Renderer(cornell64, 1, 1, max_bounces=2)
+    assert one.render(0, 3)[0][0, 0, 3] == 3
+    empty_rank = api.Renderer(cornell64, 8, 4, rank=1, world_size=2, strip_rows=4)   # a rank that owns no row
+    assert empty_rank.render(0, 2)[0].shape == (0, 8, 4)
+
+
+def test_large_frame_properties(api):
+    """BASELINE-size frame (1920x1080): properties that need no oracle — every pixel got its samples, radiance finite and
+    non-negative, escaped pixels carry exactly the ambient term, rendering twice gives the same bits."""
+    from path_tracer_amd import scenes
+    r = api.Renderer(scenes.cornell_box(1920, 1080), 1920, 1080, max_bounces=8)
+    a, pos, idb = r.render(0, 2)
+    assert (a[..., 3] == 2).all() and np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    miss = idb == ((255 << 16) | 255)
+    assert miss.any() and (~miss).any()
+    assert_bit_equal(a[miss][:, :3], np.full((miss.sum(), 3), np.float32(0.006) + np.float32(0.006), np.float32), "ambient")
+    r.reset_accumulation()
+    b, _, _ = r.render(0, 2)
+    assert_bit_equal(a, b, "re-render")

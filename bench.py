@@ -34,7 +34,7 @@ def cpu_baseline(seconds_budget=20.0):
     dt = time.perf_counter() - t0
     rays = int(ctr[0] + ctr[1] + ctr[2])
     spp = 1
-    extra = int(min(16, max(0, (seconds_budget - dt) // max(dt, 1e-3))))
+    extra = int(min(SPP - 1, max(0, (seconds_budget - dt) // max(dt, 1e-3))))
     if extra >= 1:
         t0 = time.perf_counter()
         _, _, _, ctr = o.render(WIDTH, HEIGHT, extra, first_sample=1, max_bounces=DEPTH, threads=threads)

@@ -191,10 +191,11 @@ int upload_scene(pt_ctx* c)
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
     const size_t blob_lds = c->lds_scene ? blob.size() : 0;
     uint32_t threads = 256;
-    while (threads > 64 && blob_lds + (size_t)sv.stack_entries * threads * 8 > 64 * 1024) threads >>= 1;
-    if (blob_lds + (size_t)sv.stack_entries * threads * 8 > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
+    while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
+    if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
-    const size_t lds = blob_lds + (size_t)sv.stack_entries * threads * 8;
+    const size_t lds = lds_need(threads);
     uint32_t per_cu = (uint32_t)std::min<size_t>((160 * 1024) / std::max<size_t>(lds, 1), 2048 / threads);
     per_cu = std::max(1u, std::min(per_cu, 8u));
     c->trace_blocks = (uint32_t)c->n_cus * per_cu;

@@ -24,20 +24,67 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-// one atomic per wave; returns this lane's slot when pred is set
-__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred)
+// Persistent-thread work fetch.  A single queue-head word sustains only ~88 dequeues/us on MI355X, so a wave claims a
+// private range of rays with ONE atomic and then refills its idle lanes from that range with no further traffic.
+struct WaveRange
 {
-    const uint64_t m = __ballot(pred);
-    uint32_t pos = 0;
-    if (m != 0ull)
+    uint32_t cur, end;
+    bool drained; // the global queue has no chunk left
+};
+__device__ __forceinline__ uint32_t fetch_chunk_size(uint32_t n)
+{
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t c = n / (waves * 4u);
+    c = c < 64u ? 64u : (c > 2048u ? 2048u : c);
+    return (c + 63u) & ~63u;
+}
+// returns how many of the wave's idle lanes receive a ray; lane i (rank r among idle lanes) gets ray first + r
+__device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, uint32_t n, uint32_t chunk, uint32_t n_idle, uint32_t& first)
+{
+    if (wr.cur >= wr.end && !wr.drained)
     {
-        const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        pos = base + mbcnt64(m);
+        if (lane_id() == 0u) base = atomicAdd(head, chunk);
+        base = __shfl(base, 0);
+        if (base >= n) { wr.drained = true; wr.cur = wr.end = n; }
+        else { wr.cur = base; wr.end = min(base + chunk, n); }
     }
-    return pos;
+    const uint32_t take = min(n_idle, wr.end - wr.cur);
+    first = wr.cur;
+    wr.cur += take;
+    return take;
+}
+
+// Block-wide queue append for up to four queues at once: one global atomic per queue per block (two barriers).
+struct BlockAppend
+{
+    uint32_t wave_cnt[4][4];
+    uint32_t wave_base[4][4];
+};
+__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t pos[4])
+{
+    const uint32_t wid = threadIdx.x >> 6;
+    uint64_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+        m[q] = __ballot(pred[q]);
+        if (lane_id() == 0u) sh.wave_cnt[q][wid] = (uint32_t)__popcll(m[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u)
+    {
+        const uint32_t q = threadIdx.x;
+        const uint32_t nw = blockDim.x >> 6;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nw; ++w) total += sh.wave_cnt[q][w];
+        uint32_t base = total ? atomicAdd(counters[q], total) : 0u;
+        for (uint32_t w = 0; w < nw; ++w) { sh.wave_base[q][w] = base; base += sh.wave_cnt[q][w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pos[q] = sh.wave_base[q][wid] + mbcnt64(m[q]);
+    __syncthreads(); // wave_cnt / wave_base are rewritten by the next iteration
 }
 
 __device__ __forceinline__ f3 xyz(const f4& v) { return f3{v.x, v.y, v.z}; }
@@ -161,34 +208,72 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     const uint32_t n = *n_ptr;
     const uint32_t prim_bits = sv.prim_bits;
 
-    bool active = false, pending = false, exhausted = false;
+    bool active = false, pending = false;
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bid = MISS_ID, sp = 0, blas_base = 0, inst = 0;
     bool in_blas = false;
+    WaveRange wr{0u, 0u, false};
+    const uint32_t chunk = fetch_chunk_size(n);
+    // staged material binning (CLOSEST_WORLD): finished rays wait in LDS until ~4 waves' worth can be appended at once
+    constexpr uint32_t kStageCap = 256;
+    uint32_t* const stage_idx = reinterpret_cast<uint32_t*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x * 2u +
+                                (threadIdx.x >> 6) * (2u * kStageCap);
+    uint32_t* const stage_cls = stage_idx + kStageCap;
+    uint32_t staged = 0;
+    auto flush_stage = [&]() {
+        uint32_t idx[4], cls[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+        {
+            const uint32_t k = j * 64u + lane_id();
+            idx[j] = k < staged ? stage_idx[k] : 0u;
+            cls[j] = k < staged ? stage_cls[k] : 0xffu;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < Q_COUNT; ++c)
+        {
+            uint64_t m[4];
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) { m[j] = __ballot(cls[j] == c); total += (uint32_t)__popcll(m[j]); }
+            if (total == 0u) continue;
+            uint32_t base = 0;
+            if (lane_id() == 0u) base = atomicAdd(out.n_shade + c, total);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+            {
+                if (cls[j] == c) out.q_shade[c][base + mbcnt64(m[j])] = idx[j];
+                base += (uint32_t)__popcll(m[j]);
+            }
+        }
+        staged = 0;
+    };
 
     for (;;)
     {
         uint64_t act = __ballot(active);
-        const bool service = exhausted ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        const bool no_more = wr.drained && wr.cur >= wr.end;
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
         if (service)
         {
-            // ---- flush finished lanes
-            if (__ballot(pending) != 0ull)
+            // ---- retire finished lanes
+            const uint64_t pm = __ballot(pending);
+            if (pm != 0ull)
             {
                 if (MODE == CLOSEST_WORLD)
                 {
-                    uint32_t cls = Q_TERMINAL;
-                    if (pending && bid != MISS_ID) cls = bl.inst[7u * (bid >> prim_bits) + 6u].w;
-#pragma unroll
-                    for (uint32_t c = 0; c < Q_COUNT; ++c)
+                    if (pending)
                     {
-                        const bool mine = pending && cls == c;
-                        const uint32_t pos = wave_append(out.n_shade + c, mine);
-                        if (mine) out.q_shade[c][pos] = ray_idx;
+                        out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                        const uint32_t k = staged + mbcnt64(pm);
+                        stage_idx[k] = ray_idx;
+                        stage_cls[k] = bid != MISS_ID ? bl.inst[7u * (bid >> prim_bits) + 6u].w : (uint32_t)Q_TERMINAL;
                     }
-                    if (pending) out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                    staged += (uint32_t)__popcll(pm);
+                    if (staged > kStageCap - 64u) flush_stage();
                 }
                 else if (MODE == CLOSEST_LIGHTS)
                 {
@@ -202,16 +287,15 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 }
                 pending = false;
             }
-            if (exhausted) break;
-            // ---- refill idle lanes from the queue (one atomic per wave)
+            if (no_more) break;
+            // ---- refill idle lanes from the wave's private range
             const uint64_t idle = ~act;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane_id() == 0u) base = atomicAdd(head, n_idle);
-            base = __shfl(base, 0);
-            const uint32_t mine = base + mbcnt64(idle);
-            if (!active && mine < n)
+            uint32_t first;
+            const uint32_t take = claim_rays(wr, head, n, chunk, (uint32_t)__popcll(idle), first);
+            const uint32_t rank = mbcnt64(idle);
+            if (!active && rank < take)
             {
+                const uint32_t mine = first + rank;
                 const f4 a = ra[mine], b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
@@ -236,9 +320,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 }
                 else { pending = true; }
             }
-            if (base + n_idle >= n) exhausted = true;
             act = __ballot(active);
-            if (act == 0ull) continue; // either flushes the just-missed lanes and refills again, or exits
+            if (act == 0ull) continue; // retires the lanes that missed the root box, then refills again or exits
         }
 
 #pragma unroll 1
@@ -311,6 +394,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             }
         }
     }
+    if (MODE == CLOSEST_WORLD && staged != 0u) flush_stage();
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
@@ -328,28 +412,30 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     const uint32_t stride = blockDim.x;
     const uint32_t n = *n_ptr;
 
-    bool active = false, exhausted = false;
+    bool active = false;
     uint32_t out_idx = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f;
     uint32_t sp = 0, blas_base = 0;
     bool in_blas = false;
+    WaveRange wr{0u, 0u, false};
+    const uint32_t chunk = fetch_chunk_size(n);
 
     for (;;)
     {
         uint64_t act = __ballot(active);
-        const bool service = exhausted ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        const bool no_more = wr.drained && wr.cur >= wr.end;
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
         if (service)
         {
-            if (exhausted) break;
+            if (no_more) break;
             const uint64_t idle = ~act;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane_id() == 0u) base = atomicAdd(head, n_idle);
-            base = __shfl(base, 0);
-            const uint32_t mine = base + mbcnt64(idle);
-            if (!active && mine < n)
+            uint32_t first;
+            const uint32_t take = claim_rays(wr, head, n, chunk, (uint32_t)__popcll(idle), first);
+            const uint32_t rank = mbcnt64(idle);
+            if (!active && rank < take)
             {
+                const uint32_t mine = first + rank;
                 const f4 a = ra[mine], b = rb[mine];
                 const uint32_t pid = asu(b.w);
                 out_idx = (MODE == ANY_HOOK) ? mine : pid;
@@ -377,7 +463,6 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                     else { occluded[out_idx] = 0u; } // NaN t_max: every reference box test fails -> not occluded
                 }
             }
-            if (base + n_idle >= n) exhausted = true;
             act = __ballot(active);
             if (act == 0ull) continue;
         }
@@ -606,8 +691,9 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
 template <uint32_t QCLASS>
 __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
+    __shared__ BlockAppend sh_append;
     const uint32_t n = io.ctr->n_shade[QCLASS];
-    const uint32_t total = ((n + 63u) / 64u) * 64u; // whole waves take part in the queue appends
+    const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
     {
         const bool valid = idx < n;
@@ -733,15 +819,15 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             }
             else { want_dead = (flags & FLAG_NEE_PENDING) != 0u; }
         }
-        // ---- wave-aggregated queue appends (all lanes of the wave reach these)
-        const uint32_t ps = wave_append(&io.ctr->n_shadow, want_shadow);
-        if (want_shadow) { io.rq_shadow.a[ps] = sh_a; io.rq_shadow.b[ps] = sh_b; }
-        const uint32_t pl = wave_append(&io.ctr->n_lchain, want_lchain);
-        if (want_lchain) { io.rq_lchain.a[pl] = lc_a; io.rq_lchain.b[pl] = lc_b; nee_e.w = asf(pl); }
-        const uint32_t pn = wave_append(&io.ctr_next->n_closest, want_next);
-        if (want_next) { io.rq_out.a[pn] = nx_a; io.rq_out.b[pn] = nx_b; }
-        const uint32_t pd = wave_append(&io.ctr_next->n_shade[Q_TERMINAL], want_dead);
-        if (want_dead) io.q_term_next[pd] = pid | ENTRY_DEAD;
+        // ---- block-aggregated queue appends (every thread of the block reaches this): one atomic per queue per block
+        uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
+        const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
+        uint32_t pos[4];
+        block_append4(sh_append, ctrs, preds, pos);
+        if (want_shadow) { io.rq_shadow.a[pos[0]] = sh_a; io.rq_shadow.b[pos[0]] = sh_b; }
+        if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; nee_e.w = asf(pos[1]); }
+        if (want_next) { io.rq_out.a[pos[2]] = nx_a; io.rq_out.b[pos[2]] = nx_b; }
+        if (want_dead) io.q_term_next[pos[3]] = pid | ENTRY_DEAD;
         if (valid)
         {
             io.st.pw[pid] = f4{pw.x, pw.y, pw.z, asf(draws)};
@@ -842,7 +928,8 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
 size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
-    return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4);
+    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 2 * 256 * 4 : 0; // per-wave binning stage (k_closest)
+    return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4) + stage;
 }
 
 } // namespace

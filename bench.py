@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--batch-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every launch (diagnostic, slower)")
     args = ap.parse_args()
 
     import torch
@@ -71,7 +72,7 @@ def main():
 
     strip = 4
     r = api.Renderer(scenes.cornell_box(WIDTH, HEIGHT), WIDTH, HEIGHT, max_bounces=DEPTH, rank=rank, world_size=world, strip_rows=strip,
-                     batch_spp=args.batch_spp, device=dev.index, flags=api.FLAG_TIMING)
+                     batch_spp=args.batch_spp, device=dev.index, flags=api.FLAG_TIMING | (api.FLAG_TIMING_ALL if args.time_all_kernels else 0))
     stream = torch.cuda.current_stream(dev)
     r.set_stream(stream.cuda_stream)
     n_rows = len(r.local_rows())

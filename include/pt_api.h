@@ -67,8 +67,9 @@ typedef struct pt_config
 
 enum
 {
-    PT_FLAG_TIMING = 1u,      /* bracket every kernel launch with HIP events (pt_get_stats kernel times) */
-    PT_FLAG_NO_LDS_SCENE = 2u /* force BVH reads from global memory even when the scene fits LDS */
+    PT_FLAG_TIMING = 1u,       /* bracket every world closest-hit launch with HIP events on the launch stream (ms_trace_closest) */
+    PT_FLAG_NO_LDS_SCENE = 2u, /* force BVH reads from global memory even when the scene fits LDS */
+    PT_FLAG_TIMING_ALL = 4u    /* bracket every kernel launch (adds ~10 us of idle per launch; diagnostic) */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */

@@ -22,6 +22,7 @@ from .scene_desc import CameraDesc, SceneDesc
 PT_OK = 0
 FLAG_TIMING = 1
 FLAG_NO_LDS_SCENE = 2
+FLAG_TIMING_ALL = 4
 DEFAULT_SEED = 0x5EED5EED
 
 # every symbol include/pt_api.h declares

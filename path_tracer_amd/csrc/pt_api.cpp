@@ -191,7 +191,7 @@ int upload_scene(pt_ctx* c)
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
     const size_t blob_lds = c->lds_scene ? blob.size() : 0;
     uint32_t threads = 256;
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 1024; }; // + binning stage
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -300,7 +300,8 @@ struct Timer
     int cat;
     bool on;
     size_t slot = 0;
-    Timer(pt_ctx* c_, int cat_) : c(c_), cat(cat_), on((c_->cfg.flags & PT_FLAG_TIMING) != 0)
+    Timer(pt_ctx* c_, int cat_)
+        : c(c_), cat(cat_), on((c_->cfg.flags & PT_FLAG_TIMING_ALL) != 0 || (cat_ == T_WORLD && (c_->cfg.flags & PT_FLAG_TIMING) != 0))
     {
         if (!on) return;
         if (c->ev_used == c->ev_pool.size())
@@ -437,10 +438,10 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     if (n_samples == 0 || c->local_pixels == 0) return PT_OK;
     if ((r = upload_scene(c))) return r;
     if ((r = ensure_frame(c))) return r;
-    const size_t max_paths = 24u << 20;
+    const size_t max_paths = (size_t)96 << 20; // ~100 M paths resident (~33 GB of wavefront state); ray indices are 29-bit
     uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
     batch = std::min(batch, n_samples);
-    if ((uint64_t)batch * c->local_pixels > 0x7fffffffull) return fail(c, PT_ERR_ARG, "batch too large");
+    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (ray indices are 29-bit)");
     const uint32_t n_batches = (n_samples + batch - 1) / batch;
     batch = (n_samples + n_batches - 1) / n_batches;
     if ((r = ensure_wavefront(c, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;

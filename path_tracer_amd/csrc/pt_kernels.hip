@@ -38,16 +38,31 @@ __device__ __forceinline__ uint32_t fetch_chunk_size(uint32_t n)
     c = c < 64u ? 64u : (c > 2048u ? 2048u : c);
     return (c + 63u) & ~63u;
 }
+// The first chunk of every wave is static (wave w owns rays [w*chunk, (w+1)*chunk)): a launch with few rays costs no
+// atomics at all and thousands of waves do not pile onto the head word at kernel start.  Later chunks are claimed
+// dynamically and start after the static region.
+__device__ __forceinline__ WaveRange first_range(uint32_t n, uint32_t chunk)
+{
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t lo = (uint64_t)wave * chunk;
+    WaveRange wr;
+    wr.drained = lo >= n; // then every dynamic chunk also starts past n
+    wr.cur = lo >= n ? n : (uint32_t)lo;
+    wr.end = min((uint64_t)n, lo + chunk);
+    return wr;
+}
 // returns how many of the wave's idle lanes receive a ray; lane i (rank r among idle lanes) gets ray first + r
 __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, uint32_t n, uint32_t chunk, uint32_t n_idle, uint32_t& first)
 {
     if (wr.cur >= wr.end && !wr.drained)
     {
-        uint32_t base = 0;
-        if (lane_id() == 0u) base = atomicAdd(head, chunk);
-        base = __shfl(base, 0);
+        const uint64_t static_end = (uint64_t)gridDim.x * (blockDim.x >> 6) * chunk;
+        uint32_t got = 0;
+        if (lane_id() == 0u) got = atomicAdd(head, chunk);
+        got = __shfl(got, 0);
+        const uint64_t base = static_end + got;
         if (base >= n) { wr.drained = true; wr.cur = wr.end = n; }
-        else { wr.cur = base; wr.end = min(base + chunk, n); }
+        else { wr.cur = (uint32_t)base; wr.end = (uint32_t)min((uint64_t)n, base + chunk); }
     }
     const uint32_t take = min(n_idle, wr.end - wr.cur);
     first = wr.cur;
@@ -214,22 +229,22 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bid = MISS_ID, sp = 0, blas_base = 0, inst = 0;
     bool in_blas = false;
-    WaveRange wr{0u, 0u, false};
     const uint32_t chunk = fetch_chunk_size(n);
+    WaveRange wr = first_range(n, chunk);
     // staged material binning (CLOSEST_WORLD): finished rays wait in LDS until ~4 waves' worth can be appended at once
     constexpr uint32_t kStageCap = 256;
     uint32_t* const stage_idx = reinterpret_cast<uint32_t*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x * 2u +
-                                (threadIdx.x >> 6) * (2u * kStageCap);
-    uint32_t* const stage_cls = stage_idx + kStageCap;
-    uint32_t staged = 0;
+                                (threadIdx.x >> 6) * kStageCap;
+    uint32_t staged = 0, light_hits = 0;
     auto flush_stage = [&]() {
         uint32_t idx[4], cls[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j)
         {
             const uint32_t k = j * 64u + lane_id();
-            idx[j] = k < staged ? stage_idx[k] : 0u;
-            cls[j] = k < staged ? stage_cls[k] : 0xffu;
+            const uint32_t e = k < staged ? stage_idx[k] : 0xffffffffu;
+            idx[j] = e & 0x1fffffffu;
+            cls[j] = e >> 29;
         }
 #pragma unroll
         for (uint32_t c = 0; c < Q_COUNT; ++c)
@@ -269,16 +284,15 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     {
                         out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
                         const uint32_t k = staged + mbcnt64(pm);
-                        stage_idx[k] = ray_idx;
-                        stage_cls[k] = bid != MISS_ID ? bl.inst[7u * (bid >> prim_bits) + 6u].w : (uint32_t)Q_TERMINAL;
+                        const uint32_t cls = bid != MISS_ID ? bl.inst[7u * (bid >> prim_bits) + 6u].w : (uint32_t)Q_TERMINAL;
+                        stage_idx[k] = ray_idx | (cls << 29);
                     }
                     staged += (uint32_t)__popcll(pm);
                     if (staged > kStageCap - 64u) flush_stage();
                 }
                 else if (MODE == CLOSEST_LIGHTS)
                 {
-                    const uint64_t hm = __ballot(pending && bid != MISS_ID);
-                    if (hm != 0ull && lane_id() == (uint32_t)(__ffsll((long long)hm) - 1)) atomicAdd(out.n_light_hit, (uint32_t)__popcll(hm));
+                    light_hits += (uint32_t)__popcll(__ballot(pending && bid != MISS_ID));
                     if (pending) out.hits[pid] = f4{bt, bu, bv, asf(bid)};
                 }
                 else
@@ -395,6 +409,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
         }
     }
     if (MODE == CLOSEST_WORLD && staged != 0u) flush_stage();
+    if (MODE == CLOSEST_LIGHTS && light_hits != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, light_hits);
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
@@ -418,8 +433,8 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     float t_max = 0.0f;
     uint32_t sp = 0, blas_base = 0;
     bool in_blas = false;
-    WaveRange wr{0u, 0u, false};
     const uint32_t chunk = fetch_chunk_size(n);
+    WaveRange wr = first_range(n, chunk);
 
     for (;;)
     {
@@ -928,7 +943,7 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
 size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
-    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 2 * 256 * 4 : 0; // per-wave binning stage (k_closest)
+    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 4 : 0; // per-wave binning stage (k_closest)
     return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4) + stage;
 }
 

@@ -45,6 +45,19 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"Cornell {WIDTH}x{HEIGHT}, {spp} spp of 256, depth {DEPTH}, {threads} threads, {dt:.1f} s"}
 
 
+def _profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect PMC
+    counters on itself, so this is the profiled run's figure (same workload per launch), not this run's."""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        k = d["k_closest<true, 0>"]
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": f"profiles/{files[-1]} ({k['launches']} launches at batch 43 spp)"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +141,10 @@ def main():
             "kernel_ms": {"trace_closest": st.ms_trace_closest, "trace_any": st.ms_trace_any, "trace_light": st.ms_trace_light,
                           "shade": st.ms_shade, "generate": st.ms_generate, "accumulate": st.ms_accumulate},
         }
+        tr = _profiled_traffic()
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -102,3 +102,83 @@ def cornell_mixed(width=256, height=256) -> SceneDesc:
     """Material-variety Cornell: tall box = GGX metal (main.rs:86), short box = smooth dielectric (main.rs:89)."""
     models = cornell_models(GGX.new_metal((0.1, 0.1, 0.45), 0.4), Dielectric.new((0.95, 0.95, 0.95), 1.5, None))
     return SceneDesc.new(models, reference_camera(width / height), "cornell_mixed")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Procedural meshes for BASELINE.json configs[2..4] (no Stanford / Sponza assets exist offline).  float64 numpy only uses
+# + - * / sqrt (correctly rounded everywhere) and integer hashing, so the float32 arrays are identical on every host.
+
+def _icosphere(level):
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.sqrt((v * v).sum(1, keepdims=True))
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(level):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        e.sort(axis=1)
+        key = e[:, 0] * (len(v) + 1) + e[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        a, b = uniq // (len(v) + 1), uniq % (len(v) + 1)
+        mid = v[a] + v[b]
+        mid /= np.sqrt((mid * mid).sum(1, keepdims=True))
+        m = len(v) + inv.reshape(3, -1).T  # midpoint ids of edges (01, 12, 20) per face
+        v = np.concatenate([v, mid])
+        f = np.concatenate([np.stack([f[:, 0], m[:, 0], m[:, 2]], 1), np.stack([f[:, 1], m[:, 1], m[:, 0]], 1),
+                            np.stack([f[:, 2], m[:, 2], m[:, 1]], 1), np.stack([m[:, 0], m[:, 1], m[:, 2]], 1)])
+    return v, f
+
+
+def _hash01(i):
+    x = (np.asarray(i, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(29)
+    x = (x * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(32)
+    return (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def sphere_mesh(level, centre, radius, displacement=0.0, smooth=True):
+    """Icosphere (20 * 4^level triangles), optionally displaced radially by a per-vertex hash; returns (positions, normals)."""
+    v, f = _icosphere(level)
+    if displacement:
+        v = v * (1.0 + displacement * (_hash01(np.arange(len(v))) - 0.5))[:, None]
+    p = v * radius + np.asarray(centre, dtype=np.float64)
+    tris = p[f]
+    if smooth:
+        fn = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+        vn = np.zeros_like(p)
+        for k in range(3):
+            np.add.at(vn, f[:, k], fn)
+        vn /= np.sqrt((vn * vn).sum(1, keepdims=True))
+        normals = vn[f]
+    else:
+        normals = _flat_normals(tris)
+    return tris, normals + 0.0
+
+
+def cornell_mesh(width=256, height=256, level=6, material=None) -> SceneDesc:
+    """configs[2] class: Cornell room + light + one displaced icosphere (level 6 = 81 920 triangles) — deep BLAS, BVH in HBM/L2."""
+    room = cornell_models()[:4]
+    t, n = sphere_mesh(level, (0.0, -60.0, -20.0), 160.0, displacement=0.18)
+    mesh = _model(t, n, material or Lambertian.new((0.73, 0.73, 0.73)), f"icosphere_l{level}")
+    return SceneDesc.new(room + [mesh], reference_camera(width / height), f"cornell_mesh_l{level}")
+
+
+def cornell_spheres(width=256, height=256, level=4) -> SceneDesc:
+    """configs[4] class: diffuse + dielectric + GGX-metal spheres (materials of main.rs:82-91) in the Cornell room, with an
+    instanced mirror sphere (exact 180-degree rotation) to exercise non-identity instance transforms."""
+    room = cornell_models()[:4]
+    s0 = sphere_mesh(level, (-150.0, -128.0, 60.0), 100.0)
+    s1 = sphere_mesh(level, (40.0, -108.0, 130.0), 120.0)
+    s2 = sphere_mesh(level, (140.0, -98.0, -120.0), 130.0)
+    s3 = sphere_mesh(max(level - 1, 0), (-120.0, 180.0, -150.0), 60.0)
+    rot_y_pi = np.array([[[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0]]], dtype=np.float32)  # Quat::from_rotation_y(PI) of main.rs:97, exact
+    models = room + [
+        _model(*s0, Lambertian.new((0.05, 0.05, 0.25)), "sphere_diffuse"),                       # main.rs:85
+        _model(*s1, Dielectric.new((0.95, 0.95, 0.95), 1.5, None), "sphere_glass"),              # main.rs:89
+        _model(*s2, GGX.new_metal((0.1, 0.1, 0.45), 0.4), "sphere_ggx"),                         # main.rs:86
+        Model.new(s3[0].astype(np.float32), s3[1].astype(np.float32), Specular.new((1.0, 1.0, 1.0)),   # main.rs:90
+                  np.concatenate([np.eye(3, 4, dtype=np.float32)[None], rot_y_pi]), "sphere_mirror_x2"),
+    ]
+    return SceneDesc.new(models, reference_camera(width / height), "cornell_spheres")

@@ -237,3 +237,28 @@ def test_large_frame_properties(api):
     r.reset_accumulation()
     b, _, _ = r.render(0, 2)
     assert_bit_equal(a, b, "re-render")
+
+
+@pytest.mark.parametrize("name,kw,flags", [
+    ("cornell_box", {}, 2),                      # PT_FLAG_NO_LDS_SCENE: same scene, BVH read from global memory
+    ("cornell_spheres", dict(level=3), 0),       # 4.5 k triangles, five material kinds, rotated instance
+    ("cornell_mesh", dict(level=4), 0),          # 5 k triangles
+    ("cornell_mesh", dict(level=6), 0),          # 82 k triangles (configs[2] class): deep BLAS, BVH in HBM/L2
+])
+def test_larger_scenes_bit_exact(api, oracle_mod, name, kw, flags):
+    from path_tracer_amd import scenes
+    sc = getattr(scenes, name)(64, 36, **kw)
+    r = api.Renderer(sc, 64, 36, max_bounces=6, flags=flags)
+    o = oracle_mod.Oracle(sc)
+    assert_bit_equal(r.render_samples(0, 3), o.render_samples(64, 36, 3, max_bounces=6), f"{name} per-sample radiance")
+    st = r.stats()
+    assert st.lds_scene == (1 if (name == "cornell_box" and not flags) else 0) or st.scene_bytes <= 48 * 1024
+    rng = np.random.default_rng(9)
+    n = 4000
+    O = rng.uniform(-250, 250, (n, 3)).astype(np.float32)
+    D = rng.normal(size=(n, 3)); D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    g, c = r.trace_closest(O, D), o.trace_closest(O, D)
+    for k in ("inst", "prim", "t", "u", "v"):
+        assert_bit_equal(g[k], c[k], f"{name} closest.{k}")
+    tm = rng.uniform(0, 600, n).astype(np.float32)
+    assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel-trace stats + separate --pmc passes) into profiles/<tag>_summary.md and
+profiles/<tag>_traffic.json.  Usage: tools/profile_summary.py <gpurun_out/prof dir> <tag>"""
+import json
+import os
+import re
+import sys
+
+import pandas as pd
+
+
+def short(n):
+    n = re.sub(r"pt::\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)
+
+
+def main(src, tag):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    lines = [f"# rocprofv3 summary `{tag}` (MI355X, gfx950)", ""]
+    ks = pd.read_csv(os.path.join(src, "kt", "r1_kernel_stats.csv"))
+    ks["kernel"] = ks["Name"].map(short)
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline`", "",
+              "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    for _, r in ks.iterrows():
+        lines.append(f"| {r['kernel']} | {r['Calls']} | {r['TotalDurationNs'] / 1e6:.2f} | {r['AverageNs'] / 1e3:.1f} | {r['Percentage']:.2f} |")
+    traffic = {}
+    frames = []
+    for d in sorted(os.listdir(src)):
+        f = os.path.join(src, d, "r1_counter_collection.csv")
+        if d.startswith("pmc") and os.path.exists(f):
+            frames.append(pd.read_csv(f))
+    if frames:
+        pm = pd.concat(frames)
+        pm["kernel"] = pm["Kernel_Name"].map(short)
+        g = pm.groupby(["kernel", "Counter_Name"])["Counter_Value"].sum().unstack()
+        n = pm.groupby(["kernel", "Counter_Name"])["Dispatch_Id"].nunique().unstack()
+        lines += ["", "## PMC passes (`--pmc`, one pass per counter group; bench.py --steps 1 --warmup 0 --spp 43)", "",
+                  "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
+                  "(MI355X_MICROARCH.md §HBM), so read bytes below = 2 x FETCH_SIZE x 1024.", ""]
+        cols = [c for c in ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+                            "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"] if c in g.columns]
+        lines += ["| kernel | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
+        for k, r in g.iterrows():
+            lines.append(f"| {k} | " + " | ".join(f"{r[c]:.4g}" if pd.notna(r[c]) else "" for c in cols) + " |")
+        if "SQ_ACTIVE_INST_VALU" in g.columns and "SQ_WAVE_CYCLES" in g.columns:
+            lines += ["", "| kernel | VALU-active share of wave lifetime | VALU wave-instr per wave |", "|---|---|---|"]
+            for k, r in g.iterrows():
+                if pd.notna(r.get("SQ_WAVE_CYCLES")) and r["SQ_WAVE_CYCLES"] > 0:
+                    lines.append(f"| {k} | {r['SQ_ACTIVE_INST_VALU'] / r['SQ_WAVE_CYCLES']:.3f} | {r['SQ_INSTS_VALU'] / max(r['SQ_WAVES'], 1):.0f} |")
+        for k, r in g.iterrows():
+            if "FETCH_SIZE" in g.columns and "WRITE_SIZE" in g.columns and pd.notna(r.get("FETCH_SIZE")) and pd.notna(r.get("WRITE_SIZE")):
+                launches = int(n.loc[k, "FETCH_SIZE"])
+                traffic[k] = {"launches": launches, "read_bytes_per_launch": 2 * r["FETCH_SIZE"] * 1024 / launches,
+                              "write_bytes_per_launch": r["WRITE_SIZE"] * 1024 / launches}
+                traffic[k]["hbm_bytes_per_launch"] = traffic[k]["read_bytes_per_launch"] + traffic[k]["write_bytes_per_launch"]
+    open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -161,6 +161,9 @@ typedef struct pt_stats
     uint64_t state_bytes;            /* wavefront state + queues resident in HBM */
 } pt_stats;
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+/* queue sizes of the LAST wavefront batch, one 16-word row per bounce: n_closest, -, n_shadow, -, n_lchain, -, -, n_lchain_hit,
+ * n_shade[terminal, lambert, specular, dielectric, ggx], ... (diagnostic) */
+int pt_last_batch_counters(pt_ctx* ctx, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows);
 int pt_reset_stats(pt_ctx* ctx);
 
 #ifdef __cplusplus

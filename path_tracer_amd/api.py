@@ -31,7 +31,7 @@ EXPORTS = [
     "pt_camera_matrices", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
-    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats",
+    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
         L.pt_triangle_dump.argtypes = [vp, C.c_int, u32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
+        L.pt_last_batch_counters.argtypes = [vp, vp, u32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -320,6 +321,12 @@ class Renderer:
         s = Stats()
         self._chk(self.L.pt_get_stats(self.ctx, C.byref(s)))
         return s
+
+    def last_batch_counters(self):
+        rows = np.zeros((self.cfg.max_bounces + 2, 16), np.uint32)
+        n = C.c_uint32()
+        self._chk(self.L.pt_last_batch_counters(self.ctx, _p(rows), rows.shape[0], C.byref(n)))
+        return rows[: n.value]
 
     def reset_stats(self):
         self._chk(self.L.pt_reset_stats(self.ctx))

@@ -201,7 +201,7 @@ int upload_scene(pt_ctx* c)
     c->trace_blocks = (uint32_t)c->n_cus * per_cu;
 
     for (uint32_t q = 0; q < Q_COUNT; ++q) c->class_present[q] = (q == Q_TERMINAL);
-    for (const DInstance& in : f.instances) c->class_present[in.qclass] = true;
+    for (const DInstance& in : f.instances) c->class_present[in.qclass & 0xffu] = true;
     c->scene_uploaded = true;
     c->stats.scene_bytes = blob.size();
     c->stats.lds_scene = c->lds_scene;
@@ -357,6 +357,8 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     rp.max_bounces = g.max_bounces;
     rp.n_sobol = g.n_sobol;
     rp.enable_nee = g.enable_nee;
+    rp.keep_id_from = count >= 2 ? (count - 2) * c->local_pixels : 0u;
+    rp.keep_pos_from = (count - 1) * c->local_pixels;
     rp.seed = g.seed;
     const uint32_t rows = g.max_bounces + 2;
     hipStream_t s = c->stream;
@@ -381,9 +383,9 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
             { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, b - 1); }
             { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, b - 1); }
         }
-        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b); }
+        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam); }
         for (uint32_t q = 0; q < Q_COUNT; ++q)
-            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks); }
+            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam); }
         // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
         if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
         {
@@ -400,7 +402,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, last_row - 1); }
         { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, last_row - 1); }
         { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, last_row - 1); }
-        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks); }
+        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam); }
     }
     if (samples_out) launch_store_samples(s, rp, wb, samples_out);
     else
@@ -438,7 +440,19 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     if (n_samples == 0 || c->local_pixels == 0) return PT_OK;
     if ((r = upload_scene(c))) return r;
     if ((r = ensure_frame(c))) return r;
-    const size_t max_paths = (size_t)96 << 20; // ~100 M paths resident (~33 GB of wavefront state); ray indices are 29-bit
+    // Auto batch: as many samples per pixel resident as HBM allows (fewer, larger launches: the late bounces of a small batch
+    // cannot fill 256 CUs).  ~320 B of wavefront state per path; ray indices are 29-bit.
+    size_t max_paths = (size_t)96 << 20;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        {
+            size_t held = 0;
+            for (const DevBuf& b : c->pool) held += b.bytes;
+            max_paths = (size_t)((double)(free_b + held) * 0.75 / 320.0);
+        }
+        max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
+    }
     uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
     batch = std::min(batch, n_samples);
     if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (ray indices are 29-bit)");
@@ -898,6 +912,16 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
 {
     if (!c || !out) return PT_ERR_ARG;
     *out = c->stats;
+    return PT_OK;
+}
+
+int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows)
+{
+    if (!c || !rows16 || !n_rows) return PT_ERR_ARG;
+    if (!c->h_counters) return PT_ERR_STATE;
+    const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
+    std::memcpy(rows16, c->h_counters, (size_t)rows * sizeof(Counters));
+    *n_rows = rows;
     return PT_OK;
 }
 

@@ -160,11 +160,34 @@ struct Blob
 struct LaneRay { f3 o, d, inv; };
 
 // Ray::transform(inv_matrix)  ray.rs:22-28
-__device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, const LaneRay& w, uint32_t& root)
+//
+// Identity instances (every Cornell model) take a shortcut that is bit-identical to the full arithmetic.  glam's
+// inverse of the identity has matrix3 = I (+0 zeros) and translation = -0, so for a finite vector v
+//   ((1*vx + 0*vy) + 0*vz) [+ -0]  ==  vx                      when vx != 0
+//                                  ==  zero signed by sign(vx) & sign(vy) & sign(vz)   when vx == +-0
+// (a sum of zeros is -0 only if every addend is -0); 1/v'x is then the world-space reciprocal or +-inf.
+__device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, const LaneRay& w, bool ray_finite, uint32_t& root)
 {
     const uint4* ip = bl.inst + 7u * inst;
-    const uint4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    const uint4 meta = ip[6];
+    root = meta.x;
     LaneRay r;
+    if ((meta.w & INSTANCE_IDENTITY) != 0u && ray_finite)
+    {
+        const uint32_t so = asu(w.o.x) & asu(w.o.y) & asu(w.o.z) & 0x80000000u;
+        const uint32_t sd = asu(w.d.x) & asu(w.d.y) & asu(w.d.z) & 0x80000000u;
+        r.o.x = w.o.x != 0.0f ? w.o.x : asf(so);
+        r.o.y = w.o.y != 0.0f ? w.o.y : asf(so);
+        r.o.z = w.o.z != 0.0f ? w.o.z : asf(so);
+        r.d.x = w.d.x != 0.0f ? w.d.x : asf(sd);
+        r.d.y = w.d.y != 0.0f ? w.d.y : asf(sd);
+        r.d.z = w.d.z != 0.0f ? w.d.z : asf(sd);
+        r.inv.x = w.d.x != 0.0f ? w.inv.x : asf(sd | 0x7f800000u);
+        r.inv.y = w.d.y != 0.0f ? w.inv.y : asf(sd | 0x7f800000u);
+        r.inv.z = w.d.z != 0.0f ? w.inv.z : asf(sd | 0x7f800000u);
+        return r;
+    }
+    const uint4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
     r.o.x = ((asf(r0.x) * w.o.x + asf(r0.y) * w.o.y) + asf(r0.z) * w.o.z) + asf(r0.w);
     r.o.y = ((asf(r1.x) * w.o.x + asf(r1.y) * w.o.y) + asf(r1.z) * w.o.z) + asf(r1.w);
     r.o.z = ((asf(r2.x) * w.o.x + asf(r2.y) * w.o.y) + asf(r2.z) * w.o.z) + asf(r2.w);
@@ -172,7 +195,6 @@ __device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, cons
     r.d.y = (asf(r1.x) * w.d.x + asf(r1.y) * w.d.y) + asf(r1.z) * w.d.z;
     r.d.z = (asf(r2.x) * w.d.x + asf(r2.y) * w.d.y) + asf(r2.z) * w.d.z;
     r.inv = rcp3(r.d);
-    root = ip[6].x;
     return r;
 }
 
@@ -199,7 +221,9 @@ __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __
     return b;
 }
 
-enum { CLOSEST_WORLD = 0, CLOSEST_LIGHTS = 1, CLOSEST_HOOK = 2 };
+// CLOSEST_PRIMARY = CLOSEST_WORLD for bounce 0: every ray starts at the eye (only directions are stored, ray index == path id)
+// and a miss ends the path on the spot (integrator.rs:263-266 with accumulated = 0, path_weight = 1).
+enum { CLOSEST_WORLD = 0, CLOSEST_LIGHTS = 1, CLOSEST_HOOK = 2, CLOSEST_PRIMARY = 3 };
 
 struct ClosestOut
 {
@@ -207,6 +231,12 @@ struct ClosestOut
     uint32_t* q_shade[Q_COUNT];
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
     uint32_t* n_light_hit;
+    // CLOSEST_PRIMARY
+    f3 eye;
+    f4* acc;
+    f4* first_pos;
+    uint32_t* first_id;
+    uint32_t keep_id_from, keep_pos_from; // path ids at or above these still need first_id / first_pos (last samples of the batch)
 };
 
 // ------------------------------------------------------------------------------------------------ closest hit
@@ -223,7 +253,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     const uint32_t n = *n_ptr;
     const uint32_t prim_bits = sv.prim_bits;
 
-    bool active = false, pending = false;
+    bool active = false, pending = false, ray_finite = false;
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
@@ -278,16 +308,34 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             const uint64_t pm = __ballot(pending);
             if (pm != 0ull)
             {
-                if (MODE == CLOSEST_WORLD)
+                if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
                 {
+                    uint64_t qm = pm;
+                    if (MODE == CLOSEST_PRIMARY)
+                    {
+                        // a primary miss is a finished path: accumulated = 0 + 0.006 * 1 (integrator.rs:265), defaults of :156-157
+                        const bool missed = pending && bid == MISS_ID;
+                        if (missed)
+                        {
+                            out.acc[ray_idx] = f4{0.006f, 0.006f, 0.006f, asf(0u)};
+                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
+                            if (ray_idx >= out.keep_pos_from)
+                            {
+                                const f3 far = fma3(w.d, bc3(1e5f), w.o);
+                                out.first_pos[ray_idx] = f4{far.x, far.y, far.z, 1e5f};
+                            }
+                        }
+                        qm = __ballot(pending && !missed);
+                        pending = pending && !missed;
+                    }
                     if (pending)
                     {
                         out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
-                        const uint32_t k = staged + mbcnt64(pm);
-                        const uint32_t cls = bid != MISS_ID ? bl.inst[7u * (bid >> prim_bits) + 6u].w : (uint32_t)Q_TERMINAL;
+                        const uint32_t k = staged + mbcnt64(qm);
+                        const uint32_t cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
                         stage_idx[k] = ray_idx | (cls << 29);
                     }
-                    staged += (uint32_t)__popcll(pm);
+                    staged += (uint32_t)__popcll(qm);
                     if (staged > kStageCap - 64u) flush_stage();
                 }
                 else if (MODE == CLOSEST_LIGHTS)
@@ -310,13 +358,23 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             if (!active && rank < take)
             {
                 const uint32_t mine = first + rank;
-                const f4 a = ra[mine], b = rb[mine];
+                const f4 b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
-                w.o = xyz(a);
+                if (MODE == CLOSEST_PRIMARY)
+                {
+                    w.o = out.eye;
+                    t_max = asf(0x7f800000u);
+                }
+                else
+                {
+                    const f4 a = ra[mine];
+                    w.o = xyz(a);
+                    t_max = a.w;
+                }
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
-                t_max = a.w;
+                ray_finite = finite3(w.o) && finite3(w.d);
                 bid = MISS_ID;
                 bt = asf(0x7f800000u);
                 bu = 0.0f;
@@ -399,7 +457,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             {
                 // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99
                 uint32_t blas_root;
-                ob = to_object(bl, a, w, blas_root);
+                ob = to_object(bl, a, w, ray_finite, blas_root);
                 inst = a;
                 in_blas = true;
                 blas_base = sp;
@@ -408,7 +466,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             }
         }
     }
-    if (MODE == CLOSEST_WORLD && staged != 0u) flush_stage();
+    if ((MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY) && staged != 0u) flush_stage();
     if (MODE == CLOSEST_LIGHTS && light_hits != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, light_hits);
 }
 
@@ -427,7 +485,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     const uint32_t stride = blockDim.x;
     const uint32_t n = *n_ptr;
 
-    bool active = false;
+    bool active = false, ray_finite = false;
     uint32_t out_idx = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f;
@@ -457,6 +515,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 w.o = xyz(a);
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
+                ray_finite = finite3(w.o) && finite3(w.d);
                 t_max = a.w;
                 bool go = true;
                 if (MODE == ANY_LCHAIN)
@@ -523,7 +582,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
             else
             {
                 uint32_t blas_root;
-                ob = to_object(bl, a, w, blas_root);
+                ob = to_object(bl, a, w, ray_finite, blas_root);
                 in_blas = true;
                 blas_base = sp;
                 stack[sp * stride] = blas_root;              // BLAS root IS box-tested on pop  blas.rs:262-264
@@ -548,14 +607,14 @@ __device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t p
 }
 
 // main.rs:186-199
-__global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const CameraView cam, const PathState st, const RayQueue rq, Counters* ctr)
+__global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const CameraView cam, const RayQueue rq, Counters* ctr)
 {
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid == 0u) ctr[0].n_closest = rp.n_paths;
     if (pid >= rp.n_paths) return;
     const PixelId px = path_pixel(rp, pid);
     Stream rng{stream_key(rp.seed, px.gpixel, px.sample), 0u};
-    const uint32_t seed = rng.u32();                                       // main.rs:193
+    const uint32_t seed = rng.u32();                                       // main.rs:193 (the stream's draw 0)
     float jx, jy;
     ss_sobol(rp.n_sobol, px.sample, seed, &jx, &jy);                       // main.rs:194
     const float ox = jx - 0.5f, oy = jy - 0.5f;
@@ -578,13 +637,8 @@ __global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const C
     const float rw = 1.0f / r[3];
     const f3 eye{cam.eye[0], cam.eye[1], cam.eye[2]};
     const f3 dir = unit3(f3{r[0] * rw, r[1] * rw, r[2] * rw} - eye);
-    rq.a[pid] = f4{eye.x, eye.y, eye.z, asf(0x7f800000u)};
     rq.b[pid] = f4{dir.x, dir.y, dir.z, asf(pid)};
-    st.pw[pid] = f4{1.0f, 1.0f, 1.0f, asf(rng.k)};
-    st.acc[pid] = f4{0.0f, 0.0f, 0.0f, asf(0u)};
-    const f3 far = fma3(dir, bc3(1e5f), eye);                              // integrator.rs:156
-    st.first_pos[pid] = f4{far.x, far.y, far.z, 1e5f};
-    st.first_id[pid] = 255u;                                               // integrator.rs:157
+    // no state is initialised: bounce 0 knows path_weight = 1, accumulated = 0, one draw consumed (integrator.rs:153-161)
 }
 
 struct ShadeIO
@@ -596,6 +650,7 @@ struct ShadeIO
     uint32_t* q_term_next;
     Counters* ctr;     // row of this bounce
     Counters* ctr_next;
+    f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
 };
 
 // MIS power heuristic  integrator.rs:22
@@ -669,18 +724,23 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
         if (dead) pid = entry & ~ENTRY_DEAD;
         else
         {
-            ra = io.rq_in.a[entry];
+            ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
             rb = io.rq_in.b[entry];
             hit = io.hits[entry];
             pid = asu(rb.w);
         }
-        f4 acc4 = io.st.acc[pid];
-        f3 acc = xyz(acc4);
-        uint32_t flags = asu(acc4.w);
-        resolve_nee(sv, io, pid, acc, flags);
+        f3 acc{0.0f, 0.0f, 0.0f};
+        uint32_t flags = 0u;
+        if (bounce != 0u)
+        {
+            const f4 acc4 = io.st.acc[pid];
+            acc = xyz(acc4);
+            flags = asu(acc4.w);
+            resolve_nee(sv, io, pid, acc, flags);
+        }
         if (!dead)
         {
-            const f3 pw = xyz(io.st.pw[pid]);
+            const f3 pw = bounce == 0u ? f3{1.0f, 1.0f, 1.0f} : xyz(io.st.pw[pid]);
             const uint32_t hid = asu(hit.w);
             if (hid == MISS_ID) { acc = acc + f3{0.006f, 0.006f, 0.006f} * pw; }     // integrator.rs:263-266
             else
@@ -689,9 +749,12 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
                 const DInstance& in = sv.instances[inst];
                 if (bounce == 0u)                                                     // integrator.rs:181-185
                 {
-                    const f3 p = fma3(xyz(rb), bc3(hit.x), xyz(ra));
-                    io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
-                    io.st.first_id[pid] = in.blas & 0xffu;
+                    if (pid >= rp.keep_pos_from)
+                    {
+                        const f3 p = fma3(xyz(rb), bc3(hit.x), xyz(ra));
+                        io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
+                    }
+                    if (pid >= rp.keep_id_from) io.st.first_id[pid] = in.blas & 0xffu;
                 }
                 const DMaterial& m = sv.materials[in.material];
                 if (!rp.enable_nee || (flags & FLAG_LAST_DELTA) || bounce == 0u)       // integrator.rs:209-212
@@ -721,13 +784,21 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         if (valid)
         {
             const uint32_t entry = io.entries[idx];
-            const f4 ra = io.rq_in.a[entry], rb = io.rq_in.b[entry], hit = io.hits[entry];
+            const f4 ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
+            const f4 rb = io.rq_in.b[entry], hit = io.hits[entry];
             pid = asu(rb.w);
-            const f4 acc4 = io.st.acc[pid], pw4 = io.st.pw[pid];
-            acc = xyz(acc4);
-            flags = asu(acc4.w);
+            f4 pw4{1.0f, 1.0f, 1.0f, asf(1u)}; // bounce 0: path_weight = 1, accumulated = 0, the seed draw consumed
+            acc = f3{0.0f, 0.0f, 0.0f};
+            flags = 0u;
+            if (bounce != 0u)
+            {
+                const f4 acc4 = io.st.acc[pid];
+                pw4 = io.st.pw[pid];
+                acc = xyz(acc4);
+                flags = asu(acc4.w);
+                resolve_nee(sv, io, pid, acc, flags);
+            }
             pw = xyz(pw4);
-            resolve_nee(sv, io, pid, acc, flags);
 
             const f3 ro = xyz(ra), rd = xyz(rb);
             const uint32_t hid = asu(hit.w);
@@ -739,8 +810,8 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             const f3 p = fma3(rd, bc3(hit.x), ro);                                     // r.at(hit_info.t)
             if (bounce == 0u)                                                          // integrator.rs:181-185
             {
-                io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
-                io.st.first_id[pid] = in.blas & 0xffu;
+                if (pid >= rp.keep_pos_from) io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
+                if (pid >= rp.keep_id_from) io.st.first_id[pid] = in.blas & 0xffu;
             }
             const PixelId px = path_pixel(rp, pid);
             Stream rng{stream_key(rp.seed, px.gpixel, px.sample), asu(pw4.w)};
@@ -877,7 +948,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
         const uint32_t pid = s * rp.local_pixels + lp;
         const f3 c = finalise(xyz(st.acc[pid]));
         a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
-        idv = (idv << 16) | st.first_id[pid];
+        // (id << 16) | new once per sample: only the last two samples survive in 32 bits
+        if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
     }
     accum[lp] = a;
     id[lp] = idv;
@@ -953,7 +1025,7 @@ size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb)
 {
     const uint32_t blocks = (rp.n_paths + 255u) / 256u;
-    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, wb.rq[0], wb.counters);
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.rq[0], wb.counters);
 }
 
 template <int MODE>
@@ -981,7 +1053,7 @@ static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root,
                            n_ptr, head, lhit, occluded);
 }
 
-void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam)
 {
     Counters* row = wb.counters + b;
     ClosestOut out{};
@@ -990,7 +1062,18 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     out.q_shade[Q_TERMINAL] = wb.q_term[b & 1u];
     out.n_shade = row->n_shade;
     out.n_light_hit = nullptr;
-    launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, &row->head_closest, out);
+    if (b == 0u)
+    {
+        out.eye = f3{cam.eye[0], cam.eye[1], cam.eye[2]};
+        out.acc = wb.st.acc;
+        out.first_pos = wb.st.first_pos;
+        out.first_id = wb.st.first_id;
+        out.keep_id_from = rp.keep_id_from;
+        out.keep_pos_from = rp.keep_pos_from;
+        launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, &row->head_closest, out);
+    }
+    else
+        launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, &row->head_closest, out);
 }
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -1013,9 +1096,10 @@ void launch_trace_lchain_any(hipStream_t s, const TraceLaunch& tl, const Wavefro
 }
 
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks)
+                  uint32_t grid_blocks, const CameraView& cam)
 {
     ShadeIO io{};
+    io.primary_a = f4{cam.eye[0], cam.eye[1], cam.eye[2], __builtin_inff()};
     io.st = wb.st;
     io.rq_in = wb.rq[b & 1u];
     io.rq_out = wb.rq[(b + 1u) & 1u];

@@ -438,6 +438,11 @@ int HostScene::flatten(std::string* err)
             case MAT_GGX_DIELECTRIC: d.qclass = Q_GGX; break;
             default: d.qclass = Q_TERMINAL; break;
             }
+            {
+                // bit pattern of Affine3A::IDENTITY.inverse(): unit matrix with +0 zeros, translation -0
+                static const uint32_t ident[12] = {0x3f800000u, 0, 0, 0x80000000u, 0, 0x3f800000u, 0, 0x80000000u, 0, 0, 0x3f800000u, 0x80000000u};
+                if (std::memcmp(d.inv, ident, sizeof(ident)) == 0) d.qclass |= INSTANCE_IDENTITY;
+            }
             f.instances.push_back(d);
         }
     };
@@ -462,9 +467,11 @@ int HostScene::flatten(std::string* err)
     while ((1ull << pb) < (uint64_t)std::max<uint32_t>(tri_cursor, 2)) ++pb;
     f.prim_bits = pb;
     if ((uint64_t)f.instances.size() >= (1ull << (32 - pb)) - 1) { if (err) *err = "instance x triangle id does not fit 32 bits"; return -5; }
-    // near-first DFS keeps at most one pending sibling per level: TLAS levels + BLAS levels (+1 slack, rounded to even)
+    // Exact bound of the shared traversal stack.  A node at depth d (root = 1) is popped with at most d-1 pending siblings
+    // below it and pushes at most two children, so a tree of depth D never holds more than D entries; while a BLAS is
+    // being traversed its TLAS leaf has been popped, leaving at most D_tlas - 1 TLAS entries underneath.
     const uint32_t tlas_depth = std::max(world.depth, lights.depth);
-    f.stack_entries = ((tlas_depth + max_blas_depth + 1 + 1) / 2) * 2;
+    f.stack_entries = std::max(tlas_depth, (tlas_depth > 0 ? tlas_depth - 1 : 0) + max_blas_depth);
     flat = std::move(f);
     return 0;
 }

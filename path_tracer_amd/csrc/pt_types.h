@@ -47,7 +47,7 @@ struct alignas(16) DInstance
     uint32_t root;  // absolute node index of the BLAS root
     uint32_t blas;  // BLAS (= model) index in its TLAS arena; world: first_id source   integrator.rs:184
     uint32_t material;
-    uint32_t qclass; // shade-queue class of the material (Q_*)
+    uint32_t qclass; // bits 7:0 shade-queue class of the material (Q_*), bit 8 INSTANCE_IDENTITY
 };
 static_assert(sizeof(DInstance) == 112, "");
 
@@ -79,6 +79,7 @@ struct alignas(16) DLight
 // shade-queue classes (one shading kernel each)
 enum : uint32_t { Q_TERMINAL = 0, Q_LAMBERT = 1, Q_SPECULAR = 2, Q_DIELECTRIC = 3, Q_GGX = 4, Q_COUNT = 5 };
 enum : uint32_t { ENTRY_DEAD = 0x80000000u };
+enum : uint32_t { INSTANCE_IDENTITY = 0x100u }; // inverse matrix is bit-exactly glam's inverse of the identity (I, translation -0)
 
 // per-bounce counter row (zeroed once per batch)
 struct Counters
@@ -130,6 +131,8 @@ struct RenderParams
     uint32_t batch_samples;
     uint32_t n_paths;        // local_pixels * batch_samples
     uint32_t max_bounces, n_sobol, enable_nee;
+    uint32_t keep_id_from;   // path ids >= this belong to the batch's last two samples (id history, main.rs:206)
+    uint32_t keep_pos_from;  // path ids >= this belong to the batch's last sample (first-hit position, main.rs:205)
     uint32_t pad;
     uint64_t seed;
 };

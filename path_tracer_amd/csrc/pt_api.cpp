@@ -191,7 +191,7 @@ int upload_scene(pt_ctx* c)
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
     const size_t blob_lds = c->lds_scene ? blob.size() : 0;
     uint32_t threads = 256;
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 1024; }; // + binning stage
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -274,7 +274,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
         TAKE(w.rq[k].b, n_paths * 16);
         TAKE(w.rq_lchain[k].a, n_paths * 16);
         TAKE(w.rq_lchain[k].b, n_paths * 16);
-        TAKE(w.q_term[k], n_paths * 4);
+        TAKE(w.q_term[k], n_paths * 8);
     }
     TAKE(w.rq_shadow.a, n_paths * 16);
     TAKE(w.rq_shadow.b, n_paths * 16);
@@ -282,7 +282,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     w.q_shade[Q_TERMINAL] = nullptr;
     for (uint32_t q = 1; q < Q_COUNT; ++q)
     {
-        if (c->class_present[q]) { TAKE(w.q_shade[q], n_paths * 4); }
+        if (c->class_present[q]) { TAKE(w.q_shade[q], n_paths * 8); }
         else w.q_shade[q] = nullptr;
     }
     TAKE(w.counters, (size_t)rows * sizeof(Counters));
@@ -380,8 +380,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         if (b > 0 && nee)
         {
             { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, b - 1); }
-            { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, b - 1); }
-            { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, b - 1); }
+            { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, b - 1); }
         }
         { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam); }
         for (uint32_t q = 0; q < Q_COUNT; ++q)
@@ -400,8 +399,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     if (nee)
     {
         { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, last_row - 1); }
-        { Timer t(c, T_LIGHT); launch_trace_lchain_closest(s, tl, wb, last_row - 1); }
-        { Timer t(c, T_ANY); launch_trace_lchain_any(s, tl, wb, last_row - 1); }
+        { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, last_row - 1); }
         { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam); }
     }
     if (samples_out) launch_store_samples(s, rp, wb, samples_out);
@@ -449,7 +447,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         {
             size_t held = 0;
             for (const DevBuf& b : c->pool) held += b.bytes;
-            max_paths = (size_t)((double)(free_b + held) * 0.75 / 320.0);
+            max_paths = (size_t)((double)(free_b + held) * 0.75 / 336.0);
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }

@@ -22,8 +22,8 @@ struct WavefrontBuffers
     RayQueue rq_shadow;   // explicit-light shadow rays
     RayQueue rq_lchain[2]; // BSDF-sampled NEE rays, double buffered by bounce parity (the next shading pass re-reads directions)
     f4* hits;             // world closest hits, dense by ray index
-    uint32_t* q_shade[Q_COUNT]; // Q_TERMINAL slot unused (see q_term)
-    uint32_t* q_term[2];  // terminal queue, double buffered by bounce parity
+    uint2* q_shade[Q_COUNT]; // entries {ray index, path id}; Q_TERMINAL slot unused (see q_term)
+    uint2* q_term[2];     // terminal queue {ray index | path id + ENTRY_DEAD, path id}, double buffered by bounce parity
     Counters* counters;   // [max_bounces + 2]
 };
 
@@ -32,8 +32,8 @@ void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& ca
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam);
 // NEE rays produced by the shading of bounce `b` (counter row b)
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
-void launch_trace_lchain_closest(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
-void launch_trace_lchain_any(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
+// BSDF-sampled NEE rays: closest hit against the lights TLAS, then (same kernel, same lane) any-hit against the world
+void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // shading of bounce b for one queue class
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
                   uint32_t grid_blocks, const CameraView& cam);

@@ -228,9 +228,12 @@ enum { CLOSEST_WORLD = 0, CLOSEST_LIGHTS = 1, CLOSEST_HOOK = 2, CLOSEST_PRIMARY 
 struct ClosestOut
 {
     f4* hits;              // WORLD/HOOK: dense by ray index; LIGHTS: by path id
-    uint32_t* q_shade[Q_COUNT];
+    uint2* q_shade[Q_COUNT];   // entries {ray index, path id}
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
     uint32_t* n_light_hit;
+    // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
+    uint32_t world_root;
+    uint32_t* occl_b;
     // CLOSEST_PRIMARY
     f3 eye;
     f4* acc;
@@ -259,22 +262,25 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bid = MISS_ID, sp = 0, blas_base = 0, inst = 0;
     bool in_blas = false;
+    bool any_phase = false;   // CLOSEST_LIGHTS: the lights-TLAS hit exists, now any-hit against the world (integrator.rs:103)
+    uint32_t chain_code = 0u; // 0 light visible, 1 blocked, 2 no light on the ray
     const uint32_t chunk = fetch_chunk_size(n);
     WaveRange wr = first_range(n, chunk);
     // staged material binning (CLOSEST_WORLD): finished rays wait in LDS until ~4 waves' worth can be appended at once
     constexpr uint32_t kStageCap = 256;
-    uint32_t* const stage_idx = reinterpret_cast<uint32_t*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x * 2u +
-                                (threadIdx.x >> 6) * kStageCap;
+    uint2* const stage_idx = reinterpret_cast<uint2*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x +
+                             (threadIdx.x >> 6) * kStageCap;
     uint32_t staged = 0, light_hits = 0;
     auto flush_stage = [&]() {
-        uint32_t idx[4], cls[4];
+        uint2 idx[4];
+        uint32_t cls[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j)
         {
             const uint32_t k = j * 64u + lane_id();
-            const uint32_t e = k < staged ? stage_idx[k] : 0xffffffffu;
-            idx[j] = e & 0x1fffffffu;
-            cls[j] = e >> 29;
+            const uint2 e = k < staged ? stage_idx[k] : make_uint2(0xffffffffu, 0u);
+            idx[j] = make_uint2(e.x & 0x1fffffffu, e.y);
+            cls[j] = e.x >> 29;
         }
 #pragma unroll
         for (uint32_t c = 0; c < Q_COUNT; ++c)
@@ -333,15 +339,18 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
                         const uint32_t k = staged + mbcnt64(qm);
                         const uint32_t cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
-                        stage_idx[k] = ray_idx | (cls << 29);
+                        stage_idx[k] = make_uint2(ray_idx | (cls << 29), pid);
                     }
                     staged += (uint32_t)__popcll(qm);
                     if (staged > kStageCap - 64u) flush_stage();
                 }
                 else if (MODE == CLOSEST_LIGHTS)
                 {
-                    light_hits += (uint32_t)__popcll(__ballot(pending && bid != MISS_ID));
-                    if (pending) out.hits[pid] = f4{bt, bu, bv, asf(bid)};
+                    if (pending)
+                    {
+                        out.occl_b[pid] = chain_code;
+                        if (chain_code == 0u) out.hits[pid] = f4{bt, bu, bv, asf(bid)}; // only a visible light is ever read back
+                    }
                 }
                 else
                 {
@@ -376,6 +385,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 w.inv = rcp3(w.d);
                 ray_finite = finite3(w.o) && finite3(w.d);
                 bid = MISS_ID;
+                any_phase = false;
+                chain_code = 2u;
                 bt = asf(0x7f800000u);
                 bu = 0.0f;
                 bv = 0.0f;
@@ -401,8 +412,62 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
         {
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
+            if (MODE == CLOSEST_LIGHTS && any_phase)
+            {
+                // TLAS::any_intersect on the world with t_max = light_t * (1 - EPS)   tlas.rs:111-144, blas.rs:257-294
+                if (sp == 0u) { active = false; pending = true; chain_code = 0u; continue; }
+                sp -= 1u;
+                const uint32_t id = stack[sp * stride].x;
+                const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
+                float t_enter;
+                const bool hit = in_blas ? slab(n0, n1, ob.o, ob.inv, t_max, t_enter) : slab(n0, n1, w.o, w.inv, t_max, t_enter);
+                if (!hit) continue;
+                const uint32_t ka = n0.w, kkind = n1.w >> NODE_KIND_SHIFT, kb = n1.w & NODE_PAYLOAD_MASK;
+                if (kkind == NODE_BRANCH)
+                {
+                    stack[sp * stride] = make_uint2(ka, 0u);
+                    stack[(sp + 1u) * stride] = make_uint2(kb, 0u);
+                    sp += 2u;
+                }
+                else if (kkind == NODE_TRIS)
+                {
+                    for (uint32_t k = 0; k < kb; ++k)
+                    {
+                        const uint4* tp = bl.tris + 3u * (ka + k);
+                        float td, ud, vd, det;
+                        if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
+                        {
+                            active = false;
+                            pending = true;
+                            chain_code = 1u;
+                            break;
+                        }
+                    }
+                }
+                else
+                {
+                    uint32_t blas_root;
+                    ob = to_object(bl, ka, w, ray_finite, blas_root);
+                    in_blas = true;
+                    blas_base = sp;
+                    stack[sp * stride] = make_uint2(blas_root, 0u);
+                    sp += 1u;
+                }
+                continue;
+            }
             if (sp == 0u)
             {
+                if (MODE == CLOSEST_LIGHTS && bid != MISS_ID)
+                {
+                    // integrator.rs:100-103: the light was hit; the same ray now asks the world for any blocker before it
+                    light_hits += 1u;
+                    any_phase = true;
+                    in_blas = false;
+                    t_max = bt * (1.0f - PT_EPSILON);
+                    if (t_max == t_max) { stack[0] = make_uint2(out.world_root, 0u); sp = 1u; }
+                    else { active = false; pending = true; chain_code = 0u; } // NaN t_max: every box test fails -> visible
+                    continue;
+                }
                 active = false;
                 pending = true;
                 continue;
@@ -467,7 +532,13 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
         }
     }
     if ((MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY) && staged != 0u) flush_stage();
-    if (MODE == CLOSEST_LIGHTS && light_hits != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, light_hits);
+    if (MODE == CLOSEST_LIGHTS)
+    {
+        // any-hit casts of integrator.rs:103 (per-lane tallies, one atomic per wave)
+        uint32_t total = light_hits;
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        if (total != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, total);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
@@ -646,8 +717,8 @@ struct ShadeIO
     PathState st;
     RayQueue rq_in, rq_out, rq_shadow, rq_lchain_prev, rq_lchain;
     const f4* hits;
-    const uint32_t* entries;
-    uint32_t* q_term_next;
+    const uint2* entries;
+    uint2* q_term_next;
     Counters* ctr;     // row of this bounce
     Counters* ctr_next;
     f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
@@ -685,10 +756,10 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
     f3 s{0.0f, 0.0f, 0.0f};
     if (flags & FLAG_BSDF_CAST)
     {
-        const f4 lh = io.st.lhit[pid];
-        const uint32_t lid = asu(lh.w);
-        if (lid != MISS_ID && io.st.occl_b[pid] == 0u && pw4.w > 0.0f)     // integrator.rs:100,103,108
+        if (io.st.occl_b[pid] == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
         {
+            const f4 lh = io.st.lhit[pid];
+            const uint32_t lid = asu(lh.w);
             const f4 b4 = io.st.nee_b[pid];
             const uint32_t inst = lid >> sv.prim_bits, tri = lid & ((1u << sv.prim_bits) - 1u);
             const DInstance& in = sv.instances[inst];
@@ -717,17 +788,18 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
     const uint32_t n = io.ctr->n_shade[Q_TERMINAL];
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
     {
-        const uint32_t entry = io.entries[idx];
+        const uint2 e2 = io.entries[idx];
+        const uint32_t entry = e2.x, pid = e2.y;
         const bool dead = (entry & ENTRY_DEAD) != 0u;
-        uint32_t pid;
         f4 ra{}, rb{}, hit{};
-        if (dead) pid = entry & ~ENTRY_DEAD;
-        else
+        if (!dead)
         {
-            ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
-            rb = io.rq_in.b[entry];
             hit = io.hits[entry];
-            pid = asu(rb.w);
+            if (asu(hit.w) != MISS_ID) // a miss needs neither origin nor direction
+            {
+                ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
+                rb = io.rq_in.b[entry];
+            }
         }
         f3 acc{0.0f, 0.0f, 0.0f};
         uint32_t flags = 0u;
@@ -783,10 +855,11 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint32_t draws = 0;
         if (valid)
         {
-            const uint32_t entry = io.entries[idx];
+            const uint2 e2 = io.entries[idx];
+            const uint32_t entry = e2.x;
+            pid = e2.y; // carried in the queue entry so that the state loads do not wait for the ray record
             const f4 ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
             const f4 rb = io.rq_in.b[entry], hit = io.hits[entry];
-            pid = asu(rb.w);
             f4 pw4{1.0f, 1.0f, 1.0f, asf(1u)}; // bounce 0: path_weight = 1, accumulated = 0, the seed draw consumed
             acc = f3{0.0f, 0.0f, 0.0f};
             flags = 0u;
@@ -913,7 +986,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         if (want_shadow) { io.rq_shadow.a[pos[0]] = sh_a; io.rq_shadow.b[pos[0]] = sh_b; }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; nee_e.w = asf(pos[1]); }
         if (want_next) { io.rq_out.a[pos[2]] = nx_a; io.rq_out.b[pos[2]] = nx_b; }
-        if (want_dead) io.q_term_next[pos[3]] = pid | ENTRY_DEAD;
+        if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
         if (valid)
         {
             io.st.pw[pid] = f4{pw.x, pw.y, pw.z, asf(draws)};
@@ -1015,7 +1088,7 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
 size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
-    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 4 : 0; // per-wave binning stage (k_closest)
+    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 8 : 0; // per-wave binning stage (k_closest)
     return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4) + stage;
 }
 
@@ -1080,21 +1153,17 @@ void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     Counters* row = wb.counters + b;
     launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, nullptr, wb.st.occl_e);
 }
-void launch_trace_lchain_closest(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
+void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
     ClosestOut out{};
     out.hits = wb.st.lhit;
     out.n_shade = nullptr;
     out.n_light_hit = &row->n_lchain_hit;
+    out.world_root = tl.scene.world_root;
+    out.occl_b = wb.st.occl_b;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
 }
-void launch_trace_lchain_any(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
-{
-    Counters* row = wb.counters + b;
-    launch_any_impl<ANY_LCHAIN>(s, tl, tl.scene.world_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain_any, wb.st.lhit, wb.st.occl_b);
-}
-
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
                   uint32_t grid_blocks, const CameraView& cam)
 {

@@ -74,9 +74,11 @@ def lib():
     """Load libptmi.so (building it in-tree if the sources are newer).  Raises if that is impossible."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
-        if _build.is_stale():
-            path = _build.build()
+        path = os.environ.get("PTMI_LIB")  # tuning builds only; the default is the in-tree library
+        if not path:
+            path = _build.LIB_PATH
+            if _build.is_stale():
+                path = _build.build()
         L = C.CDLL(path)
         vp, u32, f32p = C.c_void_p, C.c_uint32, C.c_void_p
         L.pt_create.restype = vp

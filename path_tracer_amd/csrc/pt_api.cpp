@@ -56,7 +56,7 @@ struct pt_ctx
     DevBuf d_accum, d_position, d_id;
 
     // wavefront
-    size_t cap_paths = 0;
+    size_t cap_paths = 0, cap_slots = 0, cap_slots_term = 0;
     uint32_t cap_rows = 0;
     std::vector<DevBuf> pool;
     WavefrontBuffers wb{};
@@ -244,6 +244,12 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     c->pool.clear();
     if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
     n_paths = std::max<size_t>(n_paths, 64);
+    // queues hold slots, not entries: every producer may leave the tail of its last region (<= 8192 slots, and <= 1/16 of the
+    // queue) as holes.  4096 producers (traversal waves / shading workgroups) bound the slack.
+    const size_t n_slots = n_paths + std::max<size_t>(n_paths / 8 + 65536, (size_t)4 << 20);
+    const size_t n_slots_term = n_paths + std::max<size_t>(n_paths / 4 + 65536, (size_t)8 << 20); // two producer groups append here
+    c->cap_slots = n_slots;
+    c->cap_slots_term = n_slots_term;
     size_t total = 0;
     auto take = [&](size_t bytes, void** out) -> int {
         DevBuf b;
@@ -270,19 +276,19 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     TAKE(w.st.first_id, n_paths * 4);
     for (int k = 0; k < 2; ++k)
     {
-        TAKE(w.rq[k].a, n_paths * 16);
-        TAKE(w.rq[k].b, n_paths * 16);
-        TAKE(w.rq_lchain[k].a, n_paths * 16);
-        TAKE(w.rq_lchain[k].b, n_paths * 16);
-        TAKE(w.q_term[k], n_paths * 8);
+        TAKE(w.rq[k].a, n_slots * 16);
+        TAKE(w.rq[k].b, n_slots * 16);
+        TAKE(w.rq_lchain[k].a, n_slots * 16);
+        TAKE(w.rq_lchain[k].b, n_slots * 16);
+        TAKE(w.q_term[k], n_slots_term * 8);
     }
-    TAKE(w.rq_shadow.a, n_paths * 16);
-    TAKE(w.rq_shadow.b, n_paths * 16);
-    TAKE(w.hits, n_paths * 16);
+    TAKE(w.rq_shadow.a, n_slots * 16);
+    TAKE(w.rq_shadow.b, n_slots * 16);
+    TAKE(w.hits, n_slots * 16);
     w.q_shade[Q_TERMINAL] = nullptr;
     for (uint32_t q = 1; q < Q_COUNT; ++q)
     {
-        if (c->class_present[q]) { TAKE(w.q_shade[q], n_paths * 8); }
+        if (c->class_present[q]) { TAKE(w.q_shade[q], n_slots * 8); }
         else w.q_shade[q] = nullptr;
     }
     TAKE(w.counters, (size_t)rows * sizeof(Counters));
@@ -414,9 +420,14 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     for (uint32_t r = 0; r < rows; ++r)
     {
         const Counters& k = c->h_counters[r];
-        c->stats.rays_closest += k.n_closest;
-        c->stats.rays_any += (uint64_t)k.n_shadow + k.n_lchain_hit;
-        c->stats.rays_light_closest += k.n_lchain;
+        // region reservations can never pass the slack the queues were allocated with; if they did, memory was overwritten
+        if (k.n_closest > c->cap_slots || k.n_shadow > c->cap_slots || k.n_lchain > c->cap_slots || k.n_shade[Q_TERMINAL] > c->cap_slots_term)
+            return fail(c, PT_ERR_LIMIT, "internal: queue region reservation exceeded its capacity");
+        for (uint32_t q = 1; q < Q_COUNT; ++q)
+            if (k.n_shade[q] > c->cap_slots) return fail(c, PT_ERR_LIMIT, "internal: shade queue reservation exceeded its capacity");
+        c->stats.rays_closest += k.valid_closest;
+        c->stats.rays_any += (uint64_t)k.valid_shadow + k.n_lchain_hit;
+        c->stats.rays_light_closest += k.valid_lchain;
     }
     c->stats.paths += rp.n_paths;
     harvest_events(c);
@@ -447,7 +458,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         {
             size_t held = 0;
             for (const DevBuf& b : c->pool) held += b.bytes;
-            max_paths = (size_t)((double)(free_b + held) * 0.75 / 336.0);
+            max_paths = (size_t)((double)(free_b + held) * 0.75 / 352.0);
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }

@@ -70,13 +70,53 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, ui
     return take;
 }
 
-// Block-wide queue append for up to four queues at once: one global atomic per queue per block (two barriers).
+// Queue appends.  A returning atomic on ONE queue-tail word sustains only some tens of millions of operations per second on
+// MI355X (price list "dequeue"), and a wavefront renderer wants ~10^9 appended entries per second, so nobody appends entry by
+// entry or even wave by wave: a producer (a traversal wave, a shading workgroup) RESERVES a private region of the output
+// queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
+// when the producer exits is filled with HOLE markers that consumers skip; the queue's counter therefore counts slots, not
+// entries.  Region size = slots_in / (producers * 16), clamped to [256, 8192]: holes stay below ~6 % of a large queue.
+enum : uint32_t { HOLE = 0xffffffffu };
+struct Region { uint32_t cur, end; };
+__device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers)
+{
+    uint32_t r = n_in / (producers * 16u);
+    r = r < 256u ? 256u : (r > 8192u ? 8192u : r);
+    return (r + 63u) & ~63u;
+}
+// wave-uniform: take `total` slots; entries ranked below `left` go to base0 + rank, the others to base1 + (rank - left)
+struct Placement { uint32_t base0, left, base1; };
+__device__ __forceinline__ uint32_t place(const Placement& p, uint32_t rank) { return rank < p.left ? p.base0 + rank : p.base1 + (rank - p.left); }
+__device__ __forceinline__ Placement wave_reserve(Region& rg, uint32_t* counter, uint32_t total, uint32_t rsize)
+{
+    Placement p{rg.cur, rg.end - rg.cur, 0u};
+    if (total > p.left)
+    {
+        uint32_t nb = 0;
+        if (lane_id() == 0u) nb = atomicAdd(counter, rsize);
+        nb = __shfl(nb, 0);
+        p.base1 = nb;
+        rg.cur = nb + (total - p.left);
+        rg.end = nb + rsize;
+    }
+    else rg.cur += total;
+    return p;
+}
+
+// Block-wide queue append for up to four queues at once: region reservation per workgroup (two barriers, no per-tile atomics).
 struct BlockAppend
 {
     uint32_t wave_cnt[4][4];
-    uint32_t wave_base[4][4];
+    uint32_t wave_rank[4][4]; // rank of the wave's first entry inside the workgroup's tile
+    Placement place[4];
+    Region region[4];         // lives across the workgroup's grid-stride iterations
 };
-__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t pos[4])
+__device__ __forceinline__ void block_append_init(BlockAppend& sh)
+{
+    if (threadIdx.x < 4u) sh.region[threadIdx.x] = Region{0u, 0u};
+    __syncthreads();
+}
+__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t rsize, uint32_t pos[4])
 {
     const uint32_t wid = threadIdx.x >> 6;
     uint64_t m[4];
@@ -92,14 +132,24 @@ __device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const c
         const uint32_t q = threadIdx.x;
         const uint32_t nw = blockDim.x >> 6;
         uint32_t total = 0;
-        for (uint32_t w = 0; w < nw; ++w) total += sh.wave_cnt[q][w];
-        uint32_t base = total ? atomicAdd(counters[q], total) : 0u;
-        for (uint32_t w = 0; w < nw; ++w) { sh.wave_base[q][w] = base; base += sh.wave_cnt[q][w]; }
+        for (uint32_t w = 0; w < nw; ++w) { sh.wave_rank[q][w] = total; total += sh.wave_cnt[q][w]; }
+        Region rg = sh.region[q];
+        Placement p{rg.cur, rg.end - rg.cur, 0u};
+        if (total > p.left)
+        {
+            const uint32_t nb = atomicAdd(counters[q], rsize);
+            p.base1 = nb;
+            rg.cur = nb + (total - p.left);
+            rg.end = nb + rsize;
+        }
+        else rg.cur += total;
+        sh.region[q] = rg;
+        sh.place[q] = p;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pos[q] = sh.wave_base[q][wid] + mbcnt64(m[q]);
-    __syncthreads(); // wave_cnt / wave_base are rewritten by the next iteration
+    for (int q = 0; q < 4; ++q) pos[q] = place(sh.place[q], sh.wave_rank[q][wid] + mbcnt64(m[q]));
+    __syncthreads(); // the shared tables are rewritten by the next iteration
 }
 
 __device__ __forceinline__ f3 xyz(const f4& v) { return f3{v.x, v.y, v.z}; }
@@ -231,6 +281,7 @@ struct ClosestOut
     uint2* q_shade[Q_COUNT];   // entries {ray index, path id}
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
     uint32_t* n_light_hit;
+    uint32_t* n_valid;     // rays actually traced (the queue counter counts slots, holes included)
     // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
     uint32_t world_root;
     uint32_t* occl_b;
@@ -270,7 +321,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     constexpr uint32_t kStageCap = 256;
     uint2* const stage_idx = reinterpret_cast<uint2*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x +
                              (threadIdx.x >> 6) * kStageCap;
-    uint32_t staged = 0, light_hits = 0;
+    uint32_t staged = 0, light_hits = 0, valid_rays = 0;
+    Region bin_region[Q_COUNT];
+#pragma unroll
+    for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
+    const uint32_t rsize = region_size(n, gridDim.x * (blockDim.x >> 6));
     auto flush_stage = [&]() {
         uint2 idx[4];
         uint32_t cls[4];
@@ -290,14 +345,13 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) { m[j] = __ballot(cls[j] == c); total += (uint32_t)__popcll(m[j]); }
             if (total == 0u) continue;
-            uint32_t base = 0;
-            if (lane_id() == 0u) base = atomicAdd(out.n_shade + c, total);
-            base = __shfl(base, 0);
+            const Placement pl = wave_reserve(bin_region[c], out.n_shade + c, total, rsize);
+            uint32_t rank0 = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j)
             {
-                if (cls[j] == c) out.q_shade[c][base + mbcnt64(m[j])] = idx[j];
-                base += (uint32_t)__popcll(m[j]);
+                if (cls[j] == c) out.q_shade[c][place(pl, rank0 + mbcnt64(m[j]))] = idx[j];
+                rank0 += (uint32_t)__popcll(m[j]);
             }
         }
         staged = 0;
@@ -370,6 +424,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 const f4 b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
+                if (pid != HOLE) {
+                valid_rays += 1u;
                 if (MODE == CLOSEST_PRIMARY)
                 {
                     w.o = out.eye;
@@ -402,6 +458,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     active = true;
                 }
                 else { pending = true; }
+                } // not a hole
             }
             act = __ballot(active);
             if (act == 0ull) continue; // retires the lanes that missed the root box, then refills again or exits
@@ -531,7 +588,20 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             }
         }
     }
-    if ((MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY) && staged != 0u) flush_stage();
+    if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
+    {
+        if (staged != 0u) flush_stage();
+        // hand back what is left of this wave's regions as holes
+#pragma unroll
+        for (uint32_t c = 0; c < Q_COUNT; ++c)
+            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) out.q_shade[c][i] = make_uint2(HOLE, 0u);
+    }
+    if (MODE != CLOSEST_HOOK)
+    {
+        uint32_t total = valid_rays;
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        if (total != 0u && lane_id() == 0u) atomicAdd(out.n_valid, total);
+    }
     if (MODE == CLOSEST_LIGHTS)
     {
         // any-hit casts of integrator.rs:103 (per-lane tallies, one atomic per wave)
@@ -547,7 +617,7 @@ enum { ANY_SHADOW = 0, ANY_LCHAIN = 1, ANY_HOOK = 2 };
 template <bool LDS_SCENE, int MODE>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
-                                              const f4* __restrict__ lhit, uint32_t* __restrict__ occluded)
+                                              const f4* __restrict__ lhit, uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid)
 {
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
@@ -557,7 +627,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     const uint32_t n = *n_ptr;
 
     bool active = false, ray_finite = false;
-    uint32_t out_idx = 0;
+    uint32_t out_idx = 0, valid_rays = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f;
     uint32_t sp = 0, blas_base = 0;
@@ -582,6 +652,8 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 const uint32_t mine = first + rank;
                 const f4 a = ra[mine], b = rb[mine];
                 const uint32_t pid = asu(b.w);
+                if (pid != HOLE) {
+                valid_rays += 1u;
                 out_idx = (MODE == ANY_HOOK) ? mine : pid;
                 w.o = xyz(a);
                 w.d = xyz(b);
@@ -607,6 +679,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                     }
                     else { occluded[out_idx] = 0u; } // NaN t_max: every reference box test fails -> not occluded
                 }
+                } // not a hole
             }
             act = __ballot(active);
             if (act == 0ull) continue;
@@ -660,6 +733,12 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 sp += 1u;
             }
         }
+    }
+    if (n_valid != nullptr)
+    {
+        uint32_t total = valid_rays;
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        if (total != 0u && lane_id() == 0u) atomicAdd(n_valid, total);
     }
 }
 
@@ -790,6 +869,7 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
     {
         const uint2 e2 = io.entries[idx];
         const uint32_t entry = e2.x, pid = e2.y;
+        if (entry == HOLE) continue;
         const bool dead = (entry & ENTRY_DEAD) != 0u;
         f4 ra{}, rb{}, hit{};
         if (!dead)
@@ -842,11 +922,16 @@ template <uint32_t QCLASS>
 __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
     __shared__ BlockAppend sh_append;
+    block_append_init(sh_append);
     const uint32_t n = io.ctr->n_shade[QCLASS];
+    const uint32_t rsize = region_size(n, gridDim.x);
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
     {
-        const bool valid = idx < n;
+        bool valid = idx < n;
+        uint2 e2 = make_uint2(HOLE, 0u);
+        if (valid) e2 = io.entries[idx];
+        valid = valid && e2.x != HOLE;
         bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
         uint32_t pid = 0, flags = 0;
@@ -855,7 +940,6 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint32_t draws = 0;
         if (valid)
         {
-            const uint2 e2 = io.entries[idx];
             const uint32_t entry = e2.x;
             pid = e2.y; // carried in the queue entry so that the state loads do not wait for the ray record
             const f4 ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
@@ -982,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
         const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
         uint32_t pos[4];
-        block_append4(sh_append, ctrs, preds, pos);
+        block_append4(sh_append, ctrs, preds, rsize, pos);
         if (want_shadow) { io.rq_shadow.a[pos[0]] = sh_a; io.rq_shadow.b[pos[0]] = sh_b; }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; nee_e.w = asf(pos[1]); }
         if (want_next) { io.rq_out.a[pos[2]] = nx_a; io.rq_out.b[pos[2]] = nx_b; }
@@ -999,6 +1083,12 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             }
         }
     }
+    // hand back what is left of this workgroup's regions as holes (ray queues: path id = HOLE)
+    const f4 hole_b{0.0f, 0.0f, 0.0f, asf(HOLE)};
+    for (uint32_t i = sh_append.region[0].cur + threadIdx.x; i < sh_append.region[0].end; i += blockDim.x) io.rq_shadow.b[i] = hole_b;
+    for (uint32_t i = sh_append.region[1].cur + threadIdx.x; i < sh_append.region[1].end; i += blockDim.x) io.rq_lchain.b[i] = hole_b;
+    for (uint32_t i = sh_append.region[2].cur + threadIdx.x; i < sh_append.region[2].end; i += blockDim.x) io.rq_out.b[i] = hole_b;
+    for (uint32_t i = sh_append.region[3].cur + threadIdx.x; i < sh_append.region[3].end; i += blockDim.x) io.q_term_next[i] = make_uint2(HOLE, 0u);
 }
 
 // integrator.rs:272-280: finite check, clamp_length_max(100), alpha 1
@@ -1115,15 +1205,15 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
-                            const f4* lhit, uint32_t* occluded)
+                            const f4* lhit, uint32_t* occluded, uint32_t* n_valid)
 {
     const size_t lds = trace_lds_bytes(tl, false);
     if (tl.lds_scene)
         hipLaunchKernelGGL((k_any<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, lhit, occluded);
+                           n_ptr, head, lhit, occluded, n_valid);
     else
         hipLaunchKernelGGL((k_any<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, lhit, occluded);
+                           n_ptr, head, lhit, occluded, n_valid);
 }
 
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam)
@@ -1135,6 +1225,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     out.q_shade[Q_TERMINAL] = wb.q_term[b & 1u];
     out.n_shade = row->n_shade;
     out.n_light_hit = nullptr;
+    out.n_valid = &row->valid_closest;
     if (b == 0u)
     {
         out.eye = f3{cam.eye[0], cam.eye[1], cam.eye[2]};
@@ -1151,7 +1242,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, nullptr, wb.st.occl_e);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, nullptr, wb.st.occl_e, &row->valid_shadow);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -1160,6 +1251,7 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     out.hits = wb.st.lhit;
     out.n_shade = nullptr;
     out.n_light_hit = &row->n_lchain_hit;
+    out.n_valid = &row->valid_lchain;
     out.world_root = tl.scene.world_root;
     out.occl_b = wb.st.occl_b;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
@@ -1214,7 +1306,7 @@ void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t ro
 void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded)
 {
     (void)n;
-    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, nullptr, occluded);
+    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, nullptr, occluded, nullptr);
 }
 void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy)
 {

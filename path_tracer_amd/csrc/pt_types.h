@@ -81,7 +81,8 @@ enum : uint32_t { Q_TERMINAL = 0, Q_LAMBERT = 1, Q_SPECULAR = 2, Q_DIELECTRIC = 
 enum : uint32_t { ENTRY_DEAD = 0x80000000u };
 enum : uint32_t { INSTANCE_IDENTITY = 0x100u }; // inverse matrix is bit-exactly glam's inverse of the identity (I, translation -0)
 
-// per-bounce counter row (zeroed once per batch)
+// per-bounce counter row (zeroed once per batch).  n_* count queue SLOTS: producers reserve regions and return the unused
+// tails as holes, so the exact ray counts are tallied separately by the consumers (valid_*).
 struct Counters
 {
     uint32_t n_closest;      // rays in the world closest-hit queue of this bounce
@@ -90,10 +91,12 @@ struct Counters
     uint32_t head_shadow;
     uint32_t n_lchain;       // BSDF-sampled NEE rays (lights TLAS closest hit, then world any hit)
     uint32_t head_lchain;
-    uint32_t head_lchain_any;
+    uint32_t valid_lchain;   // BSDF-sampled NEE rays actually traced (queue counters count slots, holes included)
     uint32_t n_lchain_hit;   // of those, how many hit a light (= any-hit casts of integrator.rs:103)
     uint32_t n_shade[Q_COUNT];
-    uint32_t pad[3];
+    uint32_t valid_closest;  // world closest-hit rays actually traced
+    uint32_t valid_shadow;   // explicit-light shadow rays actually traced
+    uint32_t pad;
 };
 static_assert(sizeof(Counters) == 64, "");
 

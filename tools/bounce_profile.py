@@ -8,6 +8,6 @@ r = api.Renderer(scenes.cornell_box(1920, 1080), 1920, 1080, max_bounces=8, batc
 r.render_device(0, spp)
 r.render_device(0, spp)
 c = r.last_batch_counters()
-print("bounce n_closest n_shadow n_lchain n_lchain_hit n_term n_lambert")
+print("bounce slots_closest valid_closest slots_shadow valid_shadow slots_lchain valid_lchain lchain_hit slots_term slots_lambert")
 for b, row in enumerate(c):
-    print(b, row[0], row[2], row[4], row[7], row[8], row[9])
+    print(b, row[0], row[13], row[2], row[14], row[4], row[6], row[7], row[8], row[9])

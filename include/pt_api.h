@@ -93,6 +93,10 @@ int pt_build(pt_ctx* ctx);
 /* ---- Camera::new / create_ray  src/camera.rs:17-31, 94-105 ---------------------------------------------------- */
 int pt_set_camera(pt_ctx* ctx, const float eye[3], const float target[3], float fov_y_deg, float aspect);
 int pt_camera_matrices(pt_ctx* ctx, float cam_to_world_3x4[12], float inv_proj_4x4_colmajor[16]);
+/* ImageHelper (src/image_helper.rs:13-17) as used on a miss, integrator.rs:256-262: equirect environment, LINEAR rgb,
+ * width*height*3 floats, row-major (the gamma-2.2 decode of load_image :25-33 is the caller's).  NULL / 0 restores the
+ * reference's `Err` branch: constant ambient 0.006 (integrator.rs:263-266). */
+int pt_set_environment(pt_ctx* ctx, uint32_t width, uint32_t height, const float* rgb_linear);
 int pt_create_ray(pt_ctx* ctx, float s, float t, float o[3], float d[3]); /* host evaluation, for tests */
 
 /* ---- the per-frame pixel loop  src/main.rs:181-207 + accumulate.wgsl:20-23 ------------------------------------- */

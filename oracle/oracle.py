@@ -50,6 +50,7 @@ def lib():
         L.pto_add_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]
         L.pto_build.argtypes = [C.c_void_p]
         L.pto_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.pto_set_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.pto_camera_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_create_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.pto_primary_ray.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -128,6 +129,13 @@ class Oracle:
 
     def set_camera(self, cam):
         self.L.pto_set_camera(self.ctx, _f3(cam.origin), _f3(cam.target), cam.fov, cam.aspect_ratio)
+
+    def set_environment(self, rgb):
+        if rgb is None:
+            self.L.pto_set_environment(self.ctx, 0, 0, None)
+        else:
+            rgb = np.ascontiguousarray(rgb, np.float32)
+            self.L.pto_set_environment(self.ctx, rgb.shape[1], rgb.shape[0], _p(rgb))
 
     def cfg(self, width, height, first_sample=0, n_samples=1, max_bounces=8, n_sobol=512, seed=DEFAULT_SEED, enable_nee=1,
             threads=0, rows=(0, 0)):

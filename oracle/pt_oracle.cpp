@@ -990,8 +990,26 @@ struct Scene
 
 } // namespace
 
+// image_helper.rs:13-17,61-88 (linear RGB; the gamma-2.2 decode of load_image :25-33 is the caller's business)
+struct EnvMap
+{
+    std::vector<V3> data;
+    uint32_t w = 0, h = 0;
+    V3 get_pixel(uint32_t x, uint32_t y) const { return data[(size_t)(y % h) * w + (x % w)]; }     // image_helper.rs:61-68
+    static uint32_t sat_u32(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (uint32_t)f); } // Rust `as u32`
+    V3 get_pixel_bilinear(float u, float v) const                                                  // image_helper.rs:71-88
+    {
+        float x = (float)w * u, y = (float)h * v;
+        uint32_t x0 = sat_u32(x), y0 = sat_u32(y);
+        float xf = x - std::trunc(x), yf = y - std::trunc(y);
+        V3 c00 = get_pixel(x0, y0), c01 = get_pixel(x0, y0 + 1u), c10 = get_pixel(x0 + 1u, y0), c11 = get_pixel(x0 + 1u, y0 + 1u);
+        return (((1.0f - xf) * (1.0f - yf)) * c00 + ((1.0f - xf) * yf) * c01 + (xf * (1.0f - yf)) * c10) + (xf * yf) * c11;
+    }
+};
+
 struct pto_ctx
 {
+    EnvMap env;
     std::vector<Material> materials;
     std::vector<ModelDesc> models;
     std::unique_ptr<Scene> scene;
@@ -1092,7 +1110,7 @@ V3 estimate_direct_bsdf(Tracer& tr, Rng& rng, const Ray& incoming_ray, const Hit
 struct Sample { V4 colour; V4 position; uint8_t id; };
 
 // integrator.rs:143-281 (env is Err in this build: the PNG is not in the repository -> constant ambient branch :263-266)
-Sample integrate(Tracer& tr, Ray r, Rng& rng, uint32_t max_bounces, bool enable_nee)
+Sample integrate(Tracer& tr, Ray r, Rng& rng, uint32_t max_bounces, bool enable_nee, const EnvMap* env)
 {
     const Scene& scene = *tr.scene;
     V3 accumulated{0, 0, 0};
@@ -1186,7 +1204,13 @@ Sample integrate(Tracer& tr, Ray r, Rng& rng, uint32_t max_bounces, bool enable_
         }
         else
         {
-            accumulated = accumulated + V3{0.006f, 0.006f, 0.006f} * path_weight;  // integrator.rs:263-266
+            if (env && env->w)                                                     // integrator.rs:256-262
+            {
+                float u = mul_add(det_atan2(r.d.x, r.d.z), FRAC_1_PI * 0.5f, 0.5f);
+                float v = mul_add(det_asin(r.d.y), -FRAC_1_PI, 0.5f);
+                accumulated = accumulated + env->get_pixel_bilinear(u, v) * path_weight;
+            }
+            else accumulated = accumulated + V3{0.006f, 0.006f, 0.006f} * path_weight;  // integrator.rs:263-266
             break;
         }
         if (b == max_bounces) break;                                               // `for b in 0..=max_bounces`
@@ -1295,6 +1319,16 @@ int pto_set_camera(pto_ctx* c, const float eye[3], const float target[3], float 
     return 0;
 }
 
+int pto_set_environment(pto_ctx* c, uint32_t w, uint32_t h, const float* rgb)
+{
+    c->env = EnvMap();
+    if (!rgb || w == 0 || h == 0) return 0;
+    c->env.w = w; c->env.h = h;
+    c->env.data.resize((size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; ++i) c->env.data[i] = V3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    return 0;
+}
+
 int pto_camera_matrices(pto_ctx* c, float m34[12], float ip[16], float rm[16])
 {
     if (!c->camera.set) return -1;
@@ -1354,7 +1388,7 @@ static int render_impl(pto_ctx* c, const pto_render_cfg* cfg, float* accum, floa
                     uint32_t sample = cfg->first_sample + s;
                     Rng rng;
                     Ray ray = primary_ray(c->camera, *cfg, pixel, sample, &rng);
-                    Sample sm = integrate(tr, ray, rng, cfg->max_bounces, cfg->enable_nee != 0);
+                    Sample sm = integrate(tr, ray, rng, cfg->max_bounces, cfg->enable_nee != 0, &c->env);
                     tr.ctr.c[5]++;
                     acc = V4{acc.x + sm.colour.x, acc.y + sm.colour.y, acc.z + sm.colour.z, acc.w + 1.0f};
                     idv = (idv << 16) | (uint32_t)sm.id;                           // main.rs:206
@@ -1396,7 +1430,7 @@ int pto_integrate(pto_ctx* c, const pto_render_cfg* cfg, const float o[3], const
     Tracer tr(c->scene.get());
     Rng rng{stream_state0(cfg->seed, pixel, sample), draws_consumed};
     Ray r = Ray::make(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]});
-    Sample s = integrate(tr, r, rng, cfg->max_bounces, cfg->enable_nee != 0);
+    Sample s = integrate(tr, r, rng, cfg->max_bounces, cfg->enable_nee != 0, &c->env);
     std::memcpy(colour, &s.colour, 16);
     std::memcpy(position, &s.position, 16);
     *id = s.id;
@@ -1544,6 +1578,8 @@ void pto_math_batch(int fn, uint32_t n, const float* a, const float* b, float* o
         case 4: out0[i] = a[i] / b[i]; break;
         case 5: out0[i] = std::sqrt(a[i]); break;
         case 6: out0[i] = det_tan(a[i]); break;
+        case 8: out0[i] = det_atan2(a[i], b[i]); break;
+        case 9: out0[i] = det_asin(a[i]); break;
         }
     }
 }

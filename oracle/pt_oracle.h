@@ -48,6 +48,8 @@ int pto_add_model(pto_ctx*, const float* positions, const float* normals, uint32
                   const float* affines, uint32_t n_inst);
 int pto_build(pto_ctx*);
 int pto_set_camera(pto_ctx*, const float eye[3], const float target[3], float fov_y_deg, float aspect);
+/* equirect environment (linear RGB, w*h*3 floats), NULL/0 => constant ambient branch integrator.rs:263-266 */
+int pto_set_environment(pto_ctx*, uint32_t w, uint32_t h, const float* rgb);
 int pto_camera_matrices(pto_ctx*, float cam_to_world_3x4[12], float inv_proj_4x4[16], float ray_matrix_4x4[16]);
 int pto_create_ray(pto_ctx*, float s, float t, float o[3], float d[3]);
 int pto_primary_ray(pto_ctx*, const pto_render_cfg*, uint32_t pixel, uint32_t sample, float o[3], float d[3]);

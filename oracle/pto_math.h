@@ -150,6 +150,49 @@ static inline float det_ln(float x)
     return __builtin_fmaf(ef, 0.693359375f, r);
 }
 
+// atan / atan2 / asin (Cephes atanf / asinf layout, explicit fma): used by the equirect env lookup, integrator.rs:258-259
+static inline float det_atan_pos(float x) // x >= 0
+{
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    return y + __builtin_fmaf(p * z, x, x);
+}
+static inline float det_atan2(float y, float x)
+{
+    if (x != x || y != y) return NAN;
+    const float PI_ = 3.14159265358979323846f, PIO2_ = 1.5707963267948966f;
+    if (x == 0.0f)
+    {
+        if (y == 0.0f) return (f2u(x) >> 31) ? ((f2u(y) >> 31) ? -PI_ : PI_) : y;
+        return (f2u(y) >> 31) ? -PIO2_ : PIO2_;
+    }
+    float a = det_atan_pos(std::fabs(y / x));
+    if (f2u(x) >> 31) a = PI_ - a;
+    return (f2u(y) >> 31) ? -a : a;
+}
+static inline float det_asin(float x)
+{
+    float a = std::fabs(x);
+    if (!(a <= 1.0f)) return NAN;
+    if (a < 1.0e-4f) return x;
+    bool big = a > 0.5f;
+    float z, t;
+    if (big) { z = 0.5f * (1.0f - a); t = std::sqrt(z); }
+    else { t = a; z = t * t; }
+    float p = __builtin_fmaf(4.2163199048e-2f, z, 2.4181311049e-2f);
+    p = __builtin_fmaf(p, z, 4.5470025998e-2f);
+    p = __builtin_fmaf(p, z, 7.4953002686e-2f);
+    p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+    float r = __builtin_fmaf(p * z, t, t);
+    if (big) { r = r + r; r = 1.5707963267948966f - r; }
+    return (f2u(x) >> 31) ? -r : r;
+}
+
 // glibc hypotf: sqrt of the exact binary64 sum of squares, rounded once to binary32.
 static inline float det_hypot(float a, float b)
 {

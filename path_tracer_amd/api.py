@@ -28,7 +28,7 @@ DEFAULT_SEED = 0x5EED5EED
 # every symbol include/pt_api.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_build", "pt_set_camera",
-    "pt_camera_matrices", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
+    "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
@@ -92,6 +92,7 @@ def lib():
         L.pt_build.argtypes = [vp]
         L.pt_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
         L.pt_camera_matrices.argtypes = [vp, vp, vp]
+        L.pt_set_environment.argtypes = [vp, u32, u32, vp]
         L.pt_create_ray.argtypes = [vp, C.c_float, C.c_float, vp, vp]
         L.pt_render.argtypes = [vp, u32, u32, vp, vp, vp]
         L.pt_render_device.argtypes = [vp, u32, u32]
@@ -181,6 +182,14 @@ class Renderer:
 
     def set_camera(self, cam: CameraDesc):
         self._chk(self.L.pt_set_camera(self.ctx, _f3(cam.origin), _f3(cam.target), cam.fov, cam.aspect_ratio))
+
+    def set_environment(self, rgb):
+        """rgb: (h, w, 3) linear float32 equirect image, or None for the constant-ambient branch."""
+        if rgb is None:
+            self._chk(self.L.pt_set_environment(self.ctx, 0, 0, None))
+        else:
+            rgb = np.ascontiguousarray(rgb, np.float32)
+            self._chk(self.L.pt_set_environment(self.ctx, rgb.shape[1], rgb.shape[0], _p(rgb)))
 
     def set_stream(self, hip_stream: Optional[int]):
         self._chk(self.L.pt_set_stream(self.ctx, C.c_void_p(hip_stream) if hip_stream else None))

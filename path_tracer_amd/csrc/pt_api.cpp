@@ -44,7 +44,10 @@ struct pt_ctx
 
     // scene residency
     bool scene_uploaded = false;
-    DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights;
+    DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights, d_env;
+    std::vector<f4> h_env;
+    uint32_t env_w = 0, env_h = 0;
+    bool env_uploaded = false;
     SceneView sv{};
     bool lds_scene = false;
     uint32_t block_threads = 256, trace_blocks = 1024;
@@ -186,6 +189,7 @@ int upload_scene(pt_ctx* c)
     sv.light_weight_sum = f.light_weight_sum;
     sv.blob_bytes = (uint32_t)blob.size();
     sv.stack_entries = f.stack_entries;
+    sv.has_volumes = f.has_volumes ? 1u : 0u;
 
     // launch geometry of the traversal kernels: BVH in LDS when it is small, per-lane stacks always in LDS
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
@@ -239,7 +243,8 @@ int ensure_frame(pt_ctx* c)
 
 int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
 {
-    if (c->cap_paths >= n_paths && c->cap_rows >= rows) return PT_OK;
+    const bool vstack_ok = !c->sv.has_volumes || c->wb.st.vstack != nullptr;
+    if (c->cap_paths >= n_paths && c->cap_rows >= rows && vstack_ok) return PT_OK;
     for (DevBuf& b : c->pool) dev_free(b);
     c->pool.clear();
     if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
@@ -274,6 +279,8 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     TAKE(w.st.occl_b, n_paths * 4);
     TAKE(w.st.first_pos, n_paths * 16);
     TAKE(w.st.first_id, n_paths * 4);
+    if (c->sv.has_volumes) { TAKE(w.st.vstack, n_paths * 4); }
+    else w.st.vstack = nullptr;
     for (int k = 0; k < 2; ++k)
     {
         TAKE(w.rq[k].a, n_slots * 16);
@@ -375,6 +382,20 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     cam.eye[0] = c->scene.camera.matrix.t.x;
     cam.eye[1] = c->scene.camera.matrix.t.y;
     cam.eye[2] = c->scene.camera.matrix.t.z;
+    EnvView env{};
+    if (c->env_w)
+    {
+        if (!c->env_uploaded)
+        {
+            int er = dev_alloc(c, c->d_env, c->h_env.size() * sizeof(f4));
+            if (er) return er;
+            HIPCHK(c, hipMemcpyAsync(c->d_env.p, c->h_env.data(), c->h_env.size() * sizeof(f4), hipMemcpyHostToDevice, c->stream));
+            c->env_uploaded = true;
+        }
+        env.data = (const f4*)c->d_env.p;
+        env.w = c->env_w;
+        env.h = c->env_h;
+    }
 
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
     { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
@@ -388,9 +409,9 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
             { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, b - 1); }
             { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, b - 1); }
         }
-        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam); }
+        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
         for (uint32_t q = 0; q < Q_COUNT; ++q)
-            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam); }
+            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam, env); }
         // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
         if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
         {
@@ -406,7 +427,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     {
         { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, last_row - 1); }
         { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, last_row - 1); }
-        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam); }
+        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
     }
     if (samples_out) launch_store_samples(s, rp, wb, samples_out);
     else
@@ -512,7 +533,7 @@ void pt_destroy(pt_ctx* c)
     {
         (void)hipStreamSynchronize(c->stream);
         for (DevBuf& b : c->pool) dev_free(b);
-        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_accum, &c->d_position, &c->d_id};
+        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_accum, &c->d_position, &c->d_id};
         for (DevBuf* b : bufs) dev_free(*b);
         if (c->h_counters) (void)hipHostFree(c->h_counters);
         for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -566,8 +587,7 @@ int pt_build(pt_ctx* c)
 {
     if (!c) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    for (const DMaterial& m : c->scene.materials)
-        if (m.has_volume) return fail(c, PT_ERR_LIMIT, "participating media (Option<Volume>) are not implemented in the GPU integrator yet");
+    if (c->scene.materials.size() > 255) return fail(c, PT_ERR_LIMIT, "at most 255 materials (volume stacks hold 8-bit material indices)");
     std::string err;
     int r = c->scene.build(&err);
     c->scene_uploaded = false;
@@ -580,6 +600,21 @@ int pt_set_camera(pt_ctx* c, const float eye[3], const float target[3], float fo
     if (!c || !eye || !target) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->scene.set_camera(eye, target, fov_y_deg, aspect);
+    return PT_OK;
+}
+
+int pt_set_environment(pt_ctx* c, uint32_t width, uint32_t height, const float* rgb_linear)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->env_uploaded = false;
+    c->h_env.clear();
+    c->env_w = c->env_h = 0;
+    if (!rgb_linear || width == 0 || height == 0) return PT_OK;
+    c->h_env.resize((size_t)width * height);
+    for (size_t i = 0; i < c->h_env.size(); ++i) c->h_env[i] = f4{rgb_linear[3 * i], rgb_linear[3 * i + 1], rgb_linear[3 * i + 2], 0.0f};
+    c->env_w = width;
+    c->env_h = height;
     return PT_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pt_materials.h"
 #include "pt_types.h"
 
 namespace pt {
@@ -29,14 +30,15 @@ struct WavefrontBuffers
 
 void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb);
 // closest hit against the world TLAS for bounce `b`: reads rq[b&1], writes hits + shade queues of row b
-void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam);
+void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
+                        const EnvView& env);
 // NEE rays produced by the shading of bounce `b` (counter row b)
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // BSDF-sampled NEE rays: closest hit against the lights TLAS, then (same kernel, same lane) any-hit against the world
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // shading of bounce b for one queue class
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam);
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env);
 // accum[pixel] += sum over batch samples in order of (finalised rgb, 1); position/id of the last samples
 void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
                        uint32_t write_position);

@@ -291,6 +291,7 @@ struct ClosestOut
     f4* first_pos;
     uint32_t* first_id;
     uint32_t keep_id_from, keep_pos_from; // path ids at or above these still need first_id / first_pos (last samples of the batch)
+    uint32_t finalize_miss;               // 0 when an environment map is set: misses then go to the terminal queue like any bounce
 };
 
 // ------------------------------------------------------------------------------------------------ closest hit
@@ -374,10 +375,20 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     if (MODE == CLOSEST_PRIMARY)
                     {
                         // a primary miss is a finished path: accumulated = 0 + 0.006 * 1 (integrator.rs:265), defaults of :156-157
-                        const bool missed = pending && bid == MISS_ID;
+                        const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
                         if (missed)
                         {
                             out.acc[ray_idx] = f4{0.006f, 0.006f, 0.006f, asf(0u)};
+                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
+                            if (ray_idx >= out.keep_pos_from)
+                            {
+                                const f3 far = fma3(w.d, bc3(1e5f), w.o);
+                                out.first_pos[ray_idx] = f4{far.x, far.y, far.z, 1e5f};
+                            }
+                        }
+                        else if (pending && bid == MISS_ID)
+                        {
+                            // environment map present: the terminal pass shades the miss; defaults of integrator.rs:156-157 still apply
                             if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
                             if (ray_idx >= out.keep_pos_from)
                             {
@@ -801,6 +812,7 @@ struct ShadeIO
     Counters* ctr;     // row of this bounce
     Counters* ctr_next;
     f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
+    EnvView env;       // equirect environment for misses (w == 0: constant ambient, integrator.rs:263-266)
 };
 
 // MIS power heuristic  integrator.rs:22
@@ -875,11 +887,12 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
         if (!dead)
         {
             hit = io.hits[entry];
-            if (asu(hit.w) != MISS_ID) // a miss needs neither origin nor direction
+            if (asu(hit.w) != MISS_ID) // a miss needs no origin, and its direction only for the environment lookup
             {
                 ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
                 rb = io.rq_in.b[entry];
             }
+            else if (io.env.w != 0u) rb = io.rq_in.b[entry];
         }
         f3 acc{0.0f, 0.0f, 0.0f};
         uint32_t flags = 0u;
@@ -894,7 +907,11 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
         {
             const f3 pw = bounce == 0u ? f3{1.0f, 1.0f, 1.0f} : xyz(io.st.pw[pid]);
             const uint32_t hid = asu(hit.w);
-            if (hid == MISS_ID) { acc = acc + f3{0.006f, 0.006f, 0.006f} * pw; }     // integrator.rs:263-266
+            if (hid == MISS_ID)
+            {
+                if (io.env.w != 0u) acc = acc + env_lookup(io.env, xyz(rb)) * pw;      // integrator.rs:256-262
+                else acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;                      // integrator.rs:263-266
+            }
             else
             {
                 const uint32_t inst = hid >> sv.prim_bits;
@@ -918,7 +935,7 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
 }
 
 // Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
-template <uint32_t QCLASS>
+template <uint32_t QCLASS, bool VOLUMES>
 __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
     __shared__ BlockAppend sh_append;
@@ -961,7 +978,12 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             const uint32_t hid = asu(hit.w);
             const uint32_t inst = hid >> sv.prim_bits, tri = hid & ((1u << sv.prim_bits) - 1u);
             const DInstance& in = sv.instances[inst];
-            const MatView mat = load_material(sv.materials, in.material);
+            MatView mat = load_material(sv.materials, in.material);
+            // the queue class fixes the material kind: let the compiler drop the other materials' code from this kernel
+            if (QCLASS == Q_LAMBERT) mat.kind = (VOLUMES && mat.kind == MAT_EMISSIVE) ? (uint32_t)MAT_EMISSIVE : (uint32_t)MAT_LAMBERTIAN;
+            else if (QCLASS == Q_SPECULAR) mat.kind = MAT_SPECULAR;
+            else if (QCLASS == Q_DIELECTRIC) mat.kind = MAT_DIELECTRIC;
+            else mat.kind = mat.kind == MAT_GGX_DIELECTRIC ? (uint32_t)MAT_GGX_DIELECTRIC : (uint32_t)MAT_GGX_METAL;
             bool front;
             const f3 normal = hit_normal(sv, inst, tri, hit.y, hit.z, rd, front);
             const f3 p = fma3(rd, bc3(hit.x), ro);                                     // r.at(hit_info.t)
@@ -975,6 +997,88 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             const f3 wi = -rd;                                                         // integrator.rs:187
             const bool is_delta = mat_is_delta(mat.kind);
 
+            // ---- participating media  integrator.rs:189-205: free-flight scattering in every volume the path is inside
+            bool scattered = false;
+            float s_t = 0.0f;
+            f3 s_dir{0.0f, 0.0f, 0.0f};
+            uint32_t vst = 0xffffffffu, vst_in = 0xffffffffu;
+            if (VOLUMES)
+            {
+                if (bounce != 0u) vst = io.st.vstack[pid];
+                vst_in = vst;
+                if (vst != 0xffffffffu)
+                {
+                    for (uint32_t slot = 0; slot < 4u; ++slot)
+                    {
+                        const uint32_t vm = (vst >> (8u * slot)) & 0xffu;
+                        if (vm == 0xffu) continue;
+                        const DMaterial& dm = sv.materials[vm];
+                        if (dm.vol_flags & 2u)                                         // VolumeScatter::scatter  volume.rs:83-97
+                        {
+                            const float t = -ln_det(rng.f32()) / dm.vol_c;
+                            if (!(t > hit.x))
+                            {
+                                const f3 d = hg_direction(dm.vol_g, rng, rd);
+                                if (!scattered || total_order_key(t) < total_order_key(s_t)) { s_t = t; s_dir = d; } // min_by(total_cmp), first wins
+                                scattered = true;
+                            }
+                        }
+                    }
+                    const float dist = scattered ? s_t : hit.x;
+                    f3 wgt{1.0f, 1.0f, 1.0f};
+                    for (uint32_t slot = 0; slot < 4u; ++slot)
+                    {
+                        const uint32_t vm = (vst >> (8u * slot)) & 0xffu;
+                        if (vm == 0xffu) continue;
+                        const DMaterial& dm = sv.materials[vm];
+                        if (dm.vol_flags & 1u) wgt = wgt * beer_lambert(f3{dm.vol_abs[0], dm.vol_abs[1], dm.vol_abs[2]}, dist);
+                    }
+                    pw = pw * wgt;
+                }
+            }
+            f3 ndir{0.0f, 0.0f, 0.0f}, next_o = p;
+            bool alive = true;
+            if (scattered)
+            {
+                // integrator.rs:196-200: the path continues from inside the medium; no surface interaction this iteration
+                flags |= FLAG_LAST_DELTA;
+                next_o = fma3(rd, bc3(s_t), ro);
+                ndir = s_dir;
+            }
+            else if (mat.kind == MAT_EMISSIVE)
+            {
+                // only reached when the scene has volumes (emissive hits are then shaded here, after the media)  integrator.rs:207-214
+                if (!rp.enable_nee || (flags & FLAG_LAST_DELTA) || bounce == 0u) acc = fma3(mat.colour, pw, acc);
+                alive = false;
+            }
+            else
+            {
+            if (VOLUMES && sv.materials[in.material].has_volume != 0u)     // integrator.rs:217-227
+            {
+                const uint32_t me = in.material & 0xffu;
+                int found = -1, empty = -1;
+                for (int slot = 0; slot < 4; ++slot)
+                {
+                    const uint32_t vm = (vst >> (8 * slot)) & 0xffu;
+                    if (vm == me && found < 0) found = slot;
+                    if (vm == 0xffu && empty < 0) empty = slot;
+                }
+                if (front) { if (found < 0 && empty >= 0) vst = (vst & ~(0xffu << (8 * empty))) | (me << (8 * empty)); }
+                else if (found >= 0)
+                {
+                    // remove and close the gap so that insertion order is kept
+                    uint32_t out_v = 0xffffffffu;
+                    int k = 0;
+                    for (int slot = 0; slot < 4; ++slot)
+                    {
+                        const uint32_t vm = (vst >> (8 * slot)) & 0xffu;
+                        if (slot == found || vm == 0xffu) continue;
+                        out_v = (out_v & ~(0xffu << (8 * k))) | (vm << (8 * k));
+                        ++k;
+                    }
+                    vst = out_v;
+                }
+            }
             if (rp.enable_nee && !is_delta)                                            // integrator.rs:231
             {
                 // ---- estimate_direct_explicit  integrator.rs:25-74
@@ -1037,13 +1141,18 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             }
 
             // ---- continuation  integrator.rs:236-251
-            const f3 ndir = mat_scatter(mat, rng, rd, normal, front);
+            ndir = mat_scatter(mat, rng, rd, normal, front);
             const BsdfSample info = mat_bsdf_pdf(mat, wi, ndir, normal, front);
-            bool alive = !(info.pdf < 0.0f);                                           // MIN_PDF = 0  integrator.rs:243
+            alive = !(info.pdf < 0.0f);                                                // MIN_PDF = 0  integrator.rs:243
             if (alive)
             {
                 pw = pw * (mat_weakening(mat.kind, ndir, normal) * info.bsdf / info.pdf); // integrator.rs:249
                 flags = is_delta ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
+            }
+            } // surface interaction
+            if (alive)
+            {
+                {
                 const uint32_t nb = bounce + 1u;
                 if (nb > rp.max_bounces) alive = false;                                 // for b in 0..=max_bounces
                 else if (nb > 3u)                                                       // Russian roulette of the next iteration  integrator.rs:166-177
@@ -1052,12 +1161,14 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
                     if (rng.f32() > survive) alive = false;
                     else pw = pw / survive;
                 }
+                }
             }
+            if (alive && VOLUMES && (vst != vst_in || bounce == 0u)) io.st.vstack[pid] = vst;
             draws = rng.k;
             if (alive)
             {
                 want_next = true;
-                nx_a = f4{p.x, p.y, p.z, asf(0x7f800000u)};
+                nx_a = f4{next_o.x, next_o.y, next_o.z, asf(0x7f800000u)};
                 nx_b = f4{ndir.x, ndir.y, ndir.z, asf(pid)};
             }
             else { want_dead = (flags & FLAG_NEE_PENDING) != 0u; }
@@ -1147,6 +1258,8 @@ __global__ void k_math_probe(int fn, uint32_t n, const float* a, const float* b,
     case 4: o0[i] = a[i] / b[i]; break;
     case 5: o0[i] = sqrtf(a[i]); break;
     case 6: o0[i] = tan_det(a[i]); break;
+    case 8: o0[i] = atan2_det(a[i], b[i]); break;
+    case 9: o0[i] = asin_det(a[i]); break;
     case 7:
     {
         Stream r{stream_key(seed, asu(a[i]), asu(b[i])), 0u};
@@ -1216,7 +1329,8 @@ static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root,
                            n_ptr, head, lhit, occluded, n_valid);
 }
 
-void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam)
+void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
+                        const EnvView& env)
 {
     Counters* row = wb.counters + b;
     ClosestOut out{};
@@ -1234,6 +1348,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         out.first_id = wb.st.first_id;
         out.keep_id_from = rp.keep_id_from;
         out.keep_pos_from = rp.keep_pos_from;
+        out.finalize_miss = env.w == 0u ? 1u : 0u;
         launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, &row->head_closest, out);
     }
     else
@@ -1257,9 +1372,10 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
 }
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam)
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env)
 {
     ShadeIO io{};
+    io.env = env;
     io.primary_a = f4{cam.eye[0], cam.eye[1], cam.eye[2], __builtin_inff()};
     io.st = wb.st;
     io.rq_in = wb.rq[b & 1u];
@@ -1275,10 +1391,22 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     switch (qclass)
     {
     case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
-    case Q_LAMBERT: hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
-    case Q_SPECULAR: hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
-    case Q_DIELECTRIC: hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
-    case Q_GGX: hipLaunchKernelGGL((k_shade_surface<Q_GGX>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
+    case Q_LAMBERT:
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        break;
+    case Q_SPECULAR:
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        break;
+    case Q_DIELECTRIC:
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        break;
+    case Q_GGX:
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        break;
     default: break;
     }
 }

@@ -109,6 +109,48 @@ PT_HD float dielectric_fresnel(float cosine, float eta)                         
     return fma_rs(pow5(1.0f - cosine), 1.0f - f0, f0);
 }
 
+// ---- participating media, material/volume.rs
+// VolumeScatter::scatter_direction (Henyey-Greenstein)  volume.rs:32-60
+PT_HD f3 hg_direction(float g, Stream& rng, f3 incoming)
+{
+    float u0 = rng.f32();
+    float u1 = rng.f32();
+    float phi = 2.0f * PT_PI * u0;
+    float z;
+    if (g == 0.0f) z = 1.0f - 2.0f * u1;
+    else
+    {
+        float x = (1.0f - g * g) / (1.0f + g * (1.0f - 2.0f * u1));
+        z = (1.0f + g * g - x * x) / (2.0f * g);
+    }
+    float sn, cs;
+    sincos_det(phi, &sn, &cs);
+    float r = sqrtf(1.0f - z * z);
+    return mul(onb_from_normal(-incoming), f3{r * cs, r * sn, z});
+}
+// VolumeAbsorption::get_transmission  volume.rs:113
+PT_HD f3 beer_lambert(f3 absorption, float dist)
+{
+    f3 e = (-absorption) * dist;
+    return f3{exp_det(e.x), exp_det(e.y), exp_det(e.z)};
+}
+// Equirect lookup of the environment on a miss  integrator.rs:256-262, image_helper.rs:61-88
+struct EnvView { const f4* data; uint32_t w, h, pad0, pad1; };
+PT_HD uint32_t sat_u32(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (uint32_t)f); } // Rust `as u32`
+PT_HD f3 env_lookup(const EnvView& env, f3 d)
+{
+    float u = fma_rs(atan2_det(d.x, d.z), PT_FRAC_1_PI * 0.5f, 0.5f);
+    float v = fma_rs(asin_det(d.y), -PT_FRAC_1_PI, 0.5f);
+    float x = (float)env.w * u, y = (float)env.h * v;
+    uint32_t x0 = sat_u32(x), y0 = sat_u32(y);
+    float xf = x - truncf(x), yf = y - truncf(y);
+    const uint32_t xa = x0 % env.w, xb = (x0 + 1u) % env.w, ya = y0 % env.h, yb = (y0 + 1u) % env.h;
+    const f4 c00 = env.data[(size_t)ya * env.w + xa], c01 = env.data[(size_t)yb * env.w + xa];
+    const f4 c10 = env.data[(size_t)ya * env.w + xb], c11 = env.data[(size_t)yb * env.w + xb];
+    const f3 a{c00.x, c00.y, c00.z}, b{c01.x, c01.y, c01.z}, c{c10.x, c10.y, c10.z}, e{c11.x, c11.y, c11.z};
+    return (((1.0f - xf) * (1.0f - yf)) * a + ((1.0f - xf) * yf) * b + (xf * (1.0f - yf)) * c) + (xf * yf) * e;
+}
+
 // MaterialTrait::scatter_direction
 PT_HD f3 mat_scatter(const MatView& m, Stream& rng, f3 incoming, f3 normal, bool front)
 {

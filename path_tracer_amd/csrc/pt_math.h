@@ -167,6 +167,48 @@ PT_HD float ln_det(float x)
     float r = m + y;
     return __builtin_fmaf(ef, 0.693359375f, r);
 }
+// atan2 / asin (Cephes atanf / asinf layout): equirect env lookup, integrator.rs:258-259
+PT_HD float atan_pos_det(float x)
+{
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    return y + __builtin_fmaf(p * z, x, x);
+}
+PT_HD float atan2_det(float y, float x)
+{
+    if (isnan_f(x) || isnan_f(y)) return from_bits(0x7fc00000u);
+    const float pi = 3.14159265358979323846f, pio2 = 1.5707963267948966f;
+    if (x == 0.0f)
+    {
+        if (y == 0.0f) return (bits(x) >> 31) ? ((bits(y) >> 31) ? -pi : pi) : y;
+        return (bits(y) >> 31) ? -pio2 : pio2;
+    }
+    float a = atan_pos_det(fabsf(y / x));
+    if (bits(x) >> 31) a = pi - a;
+    return (bits(y) >> 31) ? -a : a;
+}
+PT_HD float asin_det(float x)
+{
+    float a = fabsf(x);
+    if (!(a <= 1.0f)) return from_bits(0x7fc00000u);
+    if (a < 1.0e-4f) return x;
+    bool big = a > 0.5f;
+    float z, t;
+    if (big) { z = 0.5f * (1.0f - a); t = sqrtf(z); }
+    else { t = a; z = t * t; }
+    float p = __builtin_fmaf(4.2163199048e-2f, z, 2.4181311049e-2f);
+    p = __builtin_fmaf(p, z, 4.5470025998e-2f);
+    p = __builtin_fmaf(p, z, 7.4953002686e-2f);
+    p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+    float r = __builtin_fmaf(p * z, t, t);
+    if (big) { r = r + r; r = 1.5707963267948966f - r; }
+    return (bits(x) >> 31) ? -r : r;
+}
 PT_HD float hypot_det(float a, float b) { double da = (double)a, db = (double)b; return (float)sqrt(da * da + db * db); }
 
 // ---- counter-based WyRand (nanorand 0.7.0 constants) --------------------------------------------------------------

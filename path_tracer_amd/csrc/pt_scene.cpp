@@ -356,6 +356,7 @@ int HostScene::flatten(std::string* err)
 {
     FlatScene f;
     f.materials = materials;
+    for (const DMaterial& m : materials) f.has_volumes = f.has_volumes || m.has_volume != 0;
     // absolute node layout: world TLAS | lights TLAS | BLAS 0 | BLAS 1 | ...
     const uint32_t world_base = 0;
     const uint32_t lights_base = (uint32_t)world.nodes.size();
@@ -438,6 +439,9 @@ int HostScene::flatten(std::string* err)
             case MAT_GGX_DIELECTRIC: d.qclass = Q_GGX; break;
             default: d.qclass = Q_TERMINAL; break;
             }
+            // with participating media an emissive hit is preceded by the volume interaction (integrator.rs:189-205), which may
+            // scatter the path onwards: such hits are shaded by a surface kernel instead of the terminal pass
+            if (f.has_volumes && materials[d.material].kind == MAT_EMISSIVE) d.qclass = Q_LAMBERT;
             {
                 // bit pattern of Affine3A::IDENTITY.inverse(): unit matrix with +0 zeros, translation -0
                 static const uint32_t ident[12] = {0x3f800000u, 0, 0, 0x80000000u, 0, 0x3f800000u, 0, 0x80000000u, 0, 0, 0x3f800000u, 0x80000000u};

@@ -82,6 +82,7 @@ struct FlatScene
     uint32_t prim_bits = 0;
     uint32_t stack_entries = 0;
     float light_weight_sum = 0;
+    bool has_volumes = false;
 };
 
 class HostScene

@@ -114,6 +114,7 @@ struct SceneView
     uint32_t world_root, lights_root; // absolute node indices (MISS_ID: empty TLAS)
     uint32_t prim_bits;               // hit id = (instance << prim_bits) | triangle
     float light_weight_sum;           // LightSampler::max                         light_sampler.rs:43
+    uint32_t has_volumes;             // some material carries Some(Volume): per-path volume stacks are live
     uint32_t blob_bytes;              // nodes + tri_isect + instances, multiple of 16
     uint32_t stack_entries;           // per-lane traversal stack capacity
 };
@@ -153,6 +154,7 @@ struct PathState
     uint32_t* occl_b; // 1 = BSDF-sampled ray blocked before the light
     f4* first_pos; // first-hit xyz | t        (main.rs:205)
     uint32_t* first_id;
+    uint32_t* vstack; // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
 };
 enum : uint32_t { FLAG_BOUNCE_MASK = 0xffffu, FLAG_LAST_DELTA = 1u << 16, FLAG_NEE_PENDING = 1u << 17, FLAG_BSDF_CAST = 1u << 18 };
 

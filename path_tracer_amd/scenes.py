@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .scene_desc import Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular
+from .scene_desc import Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular, Volume
 
 
 def _quad(a, b, c, d):
@@ -182,3 +182,21 @@ def cornell_spheres(width=256, height=256, level=4) -> SceneDesc:
                   np.concatenate([np.eye(3, 4, dtype=np.float32)[None], rot_y_pi]), "sphere_mirror_x2"),
     ]
     return SceneDesc.new(models, reference_camera(width / height), "cornell_spheres")
+
+
+def cornell_media(width=256, height=256, level=3) -> SceneDesc:
+    """Participating media (material/volume.rs): the reference's own volume (main.rs:80) inside a rough-glass sphere
+    (GGX::new_dielectric, main.rs:87), a smooth glass sphere with absorption only, and a purely scattering one nested in it."""
+    room = cornell_models()[:4]
+    vol_ref = Volume.new((0.4, 0.62, 0.7), 0.1, 1.0 / 200.0, 0.6)            # main.rs:80
+    vol_abs = Volume.new((0.9, 0.2, 0.1), 0.02, 0.0, 0.0)                    # absorption only
+    vol_sca = Volume.new((0.0, 0.0, 0.0), 0.0, 1.0 / 60.0, 0.0)              # isotropic scattering only
+    s0 = sphere_mesh(level, (-120.0, -100.0, 40.0), 120.0)
+    s1 = sphere_mesh(level, (120.0, -90.0, -40.0), 135.0)
+    s2 = sphere_mesh(max(level - 1, 0), (120.0, -90.0, -40.0), 70.0)         # nested inside s1
+    models = room + [
+        _model(*s0, GGX.new_dielectric((0.95, 0.95, 0.95), 0.2, 1.5, vol_ref), "sphere_ggx_media"),
+        _model(*s1, Dielectric.new((0.95, 0.95, 0.95), 1.5, vol_abs), "sphere_glass_absorbing"),
+        _model(*s2, Dielectric.new((1.0, 1.0, 1.0), 1.3, vol_sca), "sphere_scattering_core"),
+    ]
+    return SceneDesc.new(models, reference_camera(width / height), "cornell_media")

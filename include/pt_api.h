@@ -24,7 +24,9 @@ enum pt_status
     PT_ERR_HIP = -2,      /* HIP runtime failure (no device, OOM, launch failure) */
     PT_ERR_STATE = -3,    /* call order (render before build, no camera, NEE without lights ...) */
     PT_ERR_NONRIGID = -4, /* model matrix carries scale: model.rs:40-44 asserts scale == (1,1,1) */
-    PT_ERR_LIMIT = -5     /* scene exceeds a packing limit of the device layout */
+    PT_ERR_LIMIT = -5,    /* scene exceeds a packing limit of the device layout */
+    PT_ERR_IO = -6,       /* file cannot be read */
+    PT_ERR_PARSE = -7     /* malformed OBJ (the reference panics) */
 };
 
 /* Material enum of material.rs:80-89; GGX splits into its two GGXModel variants (material.rs:176-184). */
@@ -86,6 +88,12 @@ int pt_add_material(pt_ctx* ctx, const pt_material_desc* desc);
  * affine3x4_rowmajor: n_instances rigid transforms.  Returns the model (= BLAS) index or a negative pt_status. */
 int pt_add_model(pt_ctx* ctx, const float* positions_xyz, const float* normals_xyz, uint32_t n_tris, int material,
                  const float* affine3x4_rowmajor, uint32_t n_instances);
+/* Model::new(path, ...) with the reference's own OBJ reader, load_obj blas.rs:44-131 (v / vn / f with v/vt/vn references,
+ * negative indices, fan triangulation, face-normal fallback for normal index 0).  PT_ERR_IO: file unreadable;
+ * PT_ERR_PARSE: where the reference would panic. */
+int pt_add_model_obj(pt_ctx* ctx, const char* path, int material, const float* affine3x4_rowmajor, uint32_t n_instances);
+/* triangle soup of a model as loaded (n_tris*9 floats each); pass cap_tris = 0 to query *n_tris */
+int pt_model_vertices(pt_ctx* ctx, int model, float* positions_xyz, float* normals_xyz, uint32_t cap_tris, uint32_t* n_tris);
 /* BLAS (SAH sweep, blas_bvh.rs:62-136) + world/light TLAS (agglomerative, tlas_bvh.rs:85-138) + LightSampler
  * (light_sampler.rs:41-61) on the host; flattened for the device.  No GPU is touched until the first render/trace. */
 int pt_build(pt_ctx* ctx);

@@ -48,6 +48,8 @@ def lib():
         L.pto_destroy.argtypes = [C.c_void_p]
         L.pto_add_material.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(VolumeDesc)]
         L.pto_add_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]
+        L.pto_add_model_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_uint32]
+        L.pto_model_vertices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.pto_build.argtypes = [C.c_void_p]
         L.pto_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
         L.pto_set_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -112,8 +114,11 @@ class Oracle:
             r = L.pto_add_material(self.ctx, m.kind, _f3(m.colour), m.roughness, m.ior, C.byref(vol))
             assert r >= 0
         for mod in scene_desc.models:
-            r = L.pto_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0], mats.index(mod.material),
-                                _p(mod.matrices), mod.matrices.shape[0])
+            if getattr(mod, "obj_path", None):
+                r = L.pto_add_model_obj(self.ctx, mod.obj_path.encode(), mats.index(mod.material), _p(mod.matrices), mod.matrices.shape[0])
+            else:
+                r = L.pto_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0], mats.index(mod.material),
+                                    _p(mod.matrices), mod.matrices.shape[0])
             if r < 0:
                 raise ValueError(f"pto_add_model failed: {r}")
         r = L.pto_build(self.ctx)
@@ -126,6 +131,14 @@ class Oracle:
             self.L.pto_destroy(self.ctx)
         except Exception:
             pass
+
+    def model_vertices(self, model):
+        n = C.c_uint32()
+        self.L.pto_model_vertices(self.ctx, model, None, None, 0, C.byref(n))
+        p = np.zeros((n.value, 3, 3), np.float32); nr = np.zeros((n.value, 3, 3), np.float32)
+        r = self.L.pto_model_vertices(self.ctx, model, _p(p), _p(nr), n.value, C.byref(n))
+        assert r == 0
+        return p, nr
 
     def set_camera(self, cam):
         self.L.pto_set_camera(self.ctx, _f3(cam.origin), _f3(cam.target), cam.fov, cam.aspect_ratio)

@@ -17,6 +17,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <fstream>
+#include <sstream>
+#include <string>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -1292,6 +1295,103 @@ int pto_add_model(pto_ctx* c, const float* positions, const float* normals, uint
     }
     c->models.push_back(std::move(m));
     return (int)c->models.size() - 1;
+}
+
+// load_obj, blas.rs:44-131.  Returns 0, -6 (cannot open) or -7 (where the reference would panic).
+static int load_obj(const char* path, std::vector<float>& out_p, std::vector<float>& out_n)
+{
+    std::ifstream in(path);
+    if (!in) return -6;
+    std::vector<V3> normals{V3{0, 0, 0}}, positions{V3{0, 0, 0}};                      // blas.rs:46-47
+    struct VertexRef { size_t vertex, normal; };                                       // model.rs:20-24
+    auto to_f32 = [](const std::string& t, float* v) {
+        if (t.empty() || t.find('x') != std::string::npos || t.find('X') != std::string::npos) return false;
+        size_t used = 0;
+        try { *v = std::stof(t, &used); } catch (...) { return false; }
+        return used == t.size();
+    };
+    auto to_index = [](const std::string& t, size_t len, size_t* v) {                  // blas.rs:85-92
+        if (t.empty()) return false;
+        size_t used = 0;
+        try
+        {
+            if (t[0] == '-' || t[0] == '+') { long long k = std::stoll(t, &used); *v = (size_t)((long long)len + k); }
+            else *v = (size_t)std::stoull(t, &used);
+        }
+        catch (...) { return false; }
+        return used == t.size();
+    };
+    std::string line;
+    while (std::getline(in, line))
+    {
+        std::istringstream ss(line);
+        std::vector<std::string> tokens;
+        for (std::string t; ss >> t;) tokens.push_back(t);
+        if (tokens.empty()) continue;                                                   // (reference: tokens[0] would panic)
+        if (tokens[0] == "v" || tokens[0] == "vn")                                      // blas.rs:60-75
+        {
+            V3 v;
+            if (tokens.size() < 4 || !to_f32(tokens[1], &v.x) || !to_f32(tokens[2], &v.y) || !to_f32(tokens[3], &v.z)) return -7;
+            if (tokens[0] == "v") positions.push_back(v);
+            else normals.push_back(normalize(v));
+        }
+        else if (tokens[0] == "f")                                                      // blas.rs:76-120
+        {
+            std::vector<VertexRef> refs;
+            for (size_t k = 1; k < tokens.size(); ++k)
+            {
+                std::vector<std::string> indices;
+                std::string field;
+                std::istringstream fs(tokens[k]);
+                while (std::getline(fs, field, '/')) indices.push_back(field);
+                if (!tokens[k].empty() && tokens[k].back() == '/') indices.push_back("");
+                if (indices.size() < 3) return -7;
+                VertexRef r;
+                if (!to_index(indices[0], positions.size(), &r.vertex) || !to_index(indices[2], normals.size(), &r.normal)) return -7;
+                if (r.vertex >= positions.size() || r.normal >= normals.size()) return -7;
+                refs.push_back(r);
+            }
+            for (size_t i = 1; i + 1 < refs.size(); ++i)
+            {
+                const VertexRef* tri[3] = {&refs[0], &refs[i], &refs[i + 1]};
+                for (const VertexRef* vr : tri)
+                {
+                    V3 position = positions[vr->vertex];
+                    V3 normal;
+                    if (vr->normal != 0) normal = normals[vr->normal];
+                    else
+                    {
+                        V3 u = positions[tri[1]->vertex] - positions[tri[0]->vertex];
+                        V3 v = positions[tri[2]->vertex] - positions[tri[0]->vertex];
+                        normal = cross(u, v);
+                    }
+                    out_p.push_back(position.x); out_p.push_back(position.y); out_p.push_back(position.z);
+                    out_n.push_back(normal.x); out_n.push_back(normal.y); out_n.push_back(normal.z);
+                }
+            }
+        }
+    }
+    return out_p.empty() ? -7 : 0;
+}
+
+int pto_add_model_obj(pto_ctx* c, const char* path, int material, const float* affines, uint32_t n_inst)
+{
+    std::vector<float> p, n;
+    int r = load_obj(path, p, n);
+    if (r) return r;
+    return pto_add_model(c, p.data(), n.data(), (uint32_t)(p.size() / 9), material, affines, n_inst);
+}
+
+int pto_model_vertices(pto_ctx* c, int model, float* positions, float* normals, uint32_t cap_tris, uint32_t* n_tris)
+{
+    if (model < 0 || model >= (int)c->models.size()) return -1;
+    const ModelDesc& m = c->models[model];
+    *n_tris = m.n_tris;
+    if (cap_tris == 0) return 0;
+    if (cap_tris < m.n_tris) return -1;
+    std::memcpy(positions, m.positions.data(), (size_t)m.n_tris * 36);
+    std::memcpy(normals, m.normals.data(), (size_t)m.n_tris * 36);
+    return 0;
 }
 
 int pto_build(pto_ctx* c)                                                          // scene.rs:21-35

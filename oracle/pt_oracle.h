@@ -46,6 +46,9 @@ int pto_add_material(pto_ctx*, int kind, const float colour[3], float roughness,
 /* positions/normals: n_tris*3 vertices * xyz; affines: n_inst row-major 3x4 */
 int pto_add_model(pto_ctx*, const float* positions, const float* normals, uint32_t n_tris, int material,
                   const float* affines, uint32_t n_inst);
+/* Model::new(path, ..) through load_obj, blas.rs:44-131 */
+int pto_add_model_obj(pto_ctx*, const char* path, int material, const float* affines, uint32_t n_inst);
+int pto_model_vertices(pto_ctx*, int model, float* positions, float* normals, uint32_t cap_tris, uint32_t* n_tris);
 int pto_build(pto_ctx*);
 int pto_set_camera(pto_ctx*, const float eye[3], const float target[3], float fov_y_deg, float aspect);
 /* equirect environment (linear RGB, w*h*3 floats), NULL/0 => constant ambient branch integrator.rs:263-266 */

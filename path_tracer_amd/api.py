@@ -27,7 +27,7 @@ DEFAULT_SEED = 0x5EED5EED
 
 # every symbol include/pt_api.h declares
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_build", "pt_set_camera",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
@@ -89,6 +89,8 @@ def lib():
         L.pt_set_config.argtypes = [vp, C.POINTER(Config)]
         L.pt_add_material.argtypes = [vp, C.POINTER(MaterialDesc)]
         L.pt_add_model.argtypes = [vp, f32p, f32p, u32, C.c_int, f32p, u32]
+        L.pt_add_model_obj.argtypes = [vp, C.c_char_p, C.c_int, f32p, u32]
+        L.pt_model_vertices.argtypes = [vp, C.c_int, f32p, f32p, u32, C.POINTER(u32)]
         L.pt_build.argtypes = [vp]
         L.pt_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
         L.pt_camera_matrices.argtypes = [vp, vp, vp]
@@ -152,8 +154,12 @@ class Renderer:
                 d.vol_k, d.vol_c, d.vol_g = m.volume.k, m.volume.c, m.volume.g
             self._chk(self.L.pt_add_material(self.ctx, C.byref(d)), allow_positive=True)
         for mod in scene.models:
-            self._chk(self.L.pt_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0], mats.index(mod.material),
-                                          _p(mod.matrices), mod.matrices.shape[0]), allow_positive=True)
+            if getattr(mod, "obj_path", None):
+                self._chk(self.L.pt_add_model_obj(self.ctx, mod.obj_path.encode(), mats.index(mod.material), _p(mod.matrices),
+                                                  mod.matrices.shape[0]), allow_positive=True)
+            else:
+                self._chk(self.L.pt_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0],
+                                              mats.index(mod.material), _p(mod.matrices), mod.matrices.shape[0]), allow_positive=True)
         self._chk(self.L.pt_build(self.ctx))
         if scene.camera is not None:
             self.set_camera(scene.camera)
@@ -295,6 +301,14 @@ class Renderer:
         out = np.zeros((i.shape[0], 9), np.float32)
         self._chk(self.L.pt_material_eval(self.ctx, material, i.shape[0], _p(i), _p(n), _p(f), _p(px), _p(sm), draws_consumed, _p(out)))
         return out
+
+    def model_vertices(self, model):
+        n = C.c_uint32()
+        self._chk(self.L.pt_model_vertices(self.ctx, model, None, None, 0, C.byref(n)))
+        p = np.zeros((n.value, 3, 3), np.float32)
+        nr = np.zeros((n.value, 3, 3), np.float32)
+        self._chk(self.L.pt_model_vertices(self.ctx, model, _p(p), _p(nr), n.value, C.byref(n)))
+        return p, nr
 
     # ---- host-builder introspection (CPU)
     def blas_count(self):

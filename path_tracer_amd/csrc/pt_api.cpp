@@ -583,6 +583,34 @@ int pt_add_model(pt_ctx* c, const float* positions, const float* normals, uint32
     return r;
 }
 
+int pt_add_model_obj(pt_ctx* c, const char* path, int material, const float* affines, uint32_t n_inst)
+{
+    if (!c || !path) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::string err;
+    int r = c->scene.add_model_obj(path, material, affines, n_inst, &err);
+    if (r == -4) return fail(c, PT_ERR_NONRIGID, "Model matrix can only contain translation and rotation");
+    if (r == -6) return fail(c, PT_ERR_IO, err);
+    if (r == -7) return fail(c, PT_ERR_PARSE, err);
+    if (r < 0) return fail(c, PT_ERR_ARG, "bad model description");
+    c->scene_uploaded = false;
+    return r;
+}
+
+int pt_model_vertices(pt_ctx* c, int model, float* positions, float* normals, uint32_t cap_tris, uint32_t* n_tris)
+{
+    if (!c || !n_tris) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (model < 0 || model >= (int)c->scene.models.size()) return fail(c, PT_ERR_ARG, "model index");
+    const HostModel& m = c->scene.models[model];
+    *n_tris = m.n_tris;
+    if (cap_tris == 0) return PT_OK;
+    if (cap_tris < m.n_tris || !positions || !normals) return fail(c, PT_ERR_ARG, "capacity");
+    std::memcpy(positions, m.positions.data(), (size_t)m.n_tris * 36);
+    std::memcpy(normals, m.normals.data(), (size_t)m.n_tris * 36);
+    return PT_OK;
+}
+
 int pt_build(pt_ctx* c)
 {
     if (!c) return PT_ERR_ARG;

@@ -9,8 +9,12 @@
 #include "pt_scene.h"
 
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <utility>
 
 namespace pt {
 
@@ -240,6 +244,117 @@ int HostScene::add_model(const float* positions, const float* normals, uint32_t 
     models.push_back(std::move(m));
     built = false;
     return (int)models.size() - 1;
+}
+
+// load_obj  src/tlas/tlas_bvh/blas.rs:44-131: `v`, `vn` (normalised on load), `f` with v/vt/vn references (1-based, negative =
+// relative to the end), fan triangulation, un-normalised face normal when the normal reference is 0; every other keyword is
+// skipped.  Where the reference panics (missing third reference field, unparsable number, index out of range) this returns
+// an error; blank lines are skipped (the reference would panic on `tokens[0]`).
+namespace {
+bool parse_f32(const std::string& t, float* out)
+{
+    if (t.empty() || t.find_first_of("xX") != std::string::npos) return false;
+    char* end = nullptr;
+    *out = strtof(t.c_str(), &end);
+    return end && *end == 0;
+}
+bool parse_index(const std::string& t, size_t count, size_t* out) // usize, or `len + isize` (blas.rs:85-92)
+{
+    if (t.empty()) return false;
+    char* end = nullptr;
+    if (t[0] != '-' && t[0] != '+')
+    {
+        unsigned long long v = strtoull(t.c_str(), &end, 10);
+        if (!end || *end != 0) return false;
+        *out = (size_t)v;
+        return true;
+    }
+    long long v = strtoll(t.c_str(), &end, 10);
+    if (!end || *end != 0) return false;
+    *out = (size_t)((long long)count + v);
+    return true;
+}
+} // namespace
+
+int HostScene::add_model_obj(const char* path, int material, const float* affines, uint32_t n_inst, std::string* err)
+{
+    if (!path) return -1;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { if (err) *err = std::string("cannot open ") + path; return -6; }
+    std::vector<f3> positions{f3{0, 0, 0}}, normals{f3{0, 0, 0}}; // index 0 is a dummy: OBJ indices are 1-based  blas.rs:46-47
+    std::vector<float> out_p, out_n;
+    std::string line;
+    int c;
+    size_t line_no = 0;
+    bool eof = false;
+    while (!eof)
+    {
+        line.clear();
+        while ((c = fgetc(fp)) != EOF && c != '\n') line.push_back((char)c);
+        if (c == EOF) eof = true;
+        ++line_no;
+        std::vector<std::string> tok;
+        size_t i = 0;
+        while (i < line.size())
+        {
+            while (i < line.size() && isspace((unsigned char)line[i])) ++i;
+            size_t j = i;
+            while (j < line.size() && !isspace((unsigned char)line[j])) ++j;
+            if (j > i) tok.push_back(line.substr(i, j - i));
+            i = j;
+        }
+        if (tok.empty()) continue;
+        auto bad = [&](const char* what) {
+            if (err) *err = std::string(path) + ":" + std::to_string(line_no) + ": " + what;
+            fclose(fp);
+            return -7;
+        };
+        if (tok[0] == "v" || tok[0] == "vn")
+        {
+            f3 v;
+            if (tok.size() < 4 || !parse_f32(tok[1], &v.x) || !parse_f32(tok[2], &v.y) || !parse_f32(tok[3], &v.z)) return bad("expected three numbers");
+            if (tok[0] == "v") positions.push_back(v);
+            else normals.push_back(unit3(v));                                                  // blas.rs:74
+        }
+        else if (tok[0] == "f")
+        {
+            std::vector<std::pair<size_t, size_t>> refs;
+            for (size_t k = 1; k < tok.size(); ++k)
+            {
+                std::vector<std::string> idx;
+                size_t a = 0;
+                for (;;)
+                {
+                    size_t b = tok[k].find('/', a);
+                    idx.push_back(tok[k].substr(a, b == std::string::npos ? std::string::npos : b - a));
+                    if (b == std::string::npos) break;
+                    a = b + 1;
+                }
+                size_t vi, ni;
+                if (idx.size() < 3) return bad("face reference needs v/vt/vn");                 // indices[2] panics in the reference
+                if (!parse_index(idx[0], positions.size(), &vi) || !parse_index(idx[2], normals.size(), &ni)) return bad("bad face index");
+                if (vi >= positions.size() || ni >= normals.size()) return bad("face index out of range");
+                refs.push_back({vi, ni});
+            }
+            if (refs.size() < 3) continue;                                                       // `1..(len - 1)` is empty
+            for (size_t k = 1; k + 1 < refs.size(); ++k)                                         // blas.rs:97-119
+            {
+                const std::pair<size_t, size_t> tri[3] = {refs[0], refs[k], refs[k + 1]};
+                for (const auto& r : tri)
+                {
+                    const f3 p = positions[r.first];
+                    f3 n;
+                    if (r.second != 0) n = normals[r.second];
+                    else n = cross3(positions[tri[1].first] - positions[tri[0].first], positions[tri[2].first] - positions[tri[0].first]);
+                    out_p.insert(out_p.end(), {p.x, p.y, p.z});
+                    out_n.insert(out_n.end(), {n.x, n.y, n.z});
+                }
+            }
+        }
+    }
+    fclose(fp);
+    if (out_p.empty()) { if (err) *err = std::string(path) + ": no faces"; return -7; }
+    return add_model(out_p.data(), out_n.data(), (uint32_t)(out_p.size() / 9), material, affines, n_inst);
 }
 
 void HostScene::build_blas(HostBlas& out, const HostModel& m)                           // BLAS::new  blas.rs:174-201

@@ -101,6 +101,8 @@ public:
     int add_material(int kind, const float colour[3], float roughness, float ior, bool has_volume, const float vol_abs[3], float k, float c,
                      float g);
     int add_model(const float* positions, const float* normals, uint32_t n_tris, int material, const float* affines, uint32_t n_inst);
+    // load_obj (blas.rs:44-131) + add_model; returns the model index, -1 bad argument, -4 non-rigid, -6 unreadable file, -7 parse error
+    int add_model_obj(const char* path, int material, const float* affines, uint32_t n_inst, std::string* err);
     int build(std::string* err);
     void set_camera(const float eye[3], const float target[3], float fov_deg, float aspect);
     void create_ray(float s, float t, float o[3], float d[3]) const;

@@ -98,6 +98,7 @@ class Model:
     material: Material
     matrices: np.ndarray = field(default_factory=lambda: IDENTITY_3x4[None].copy())  # [n_inst, 3, 4] row-major
     name: str = ""
+    obj_path: Optional[str] = None  # Model::new(path, ...): geometry read by the library's load_obj (blas.rs:44-131)
 
     @staticmethod
     def new(positions, normals, material: Material, matrices: Optional[Sequence] = None, name: str = "") -> "Model":
@@ -106,6 +107,13 @@ class Model:
         assert p.shape == n.shape and p.shape[0] > 0
         m = IDENTITY_3x4[None].copy() if matrices is None else np.ascontiguousarray(matrices, dtype=np.float32).reshape(-1, 3, 4)
         return Model(p, n, material, m, name)
+
+    @staticmethod
+    def from_obj(path: str, material: Material, matrices: Optional[Sequence] = None, name: str = "") -> "Model":
+        """Model::new(file_path, material, matrices) src/.../model.rs:36: the OBJ file is parsed by whoever consumes the scene."""
+        m = IDENTITY_3x4[None].copy() if matrices is None else np.ascontiguousarray(matrices, dtype=np.float32).reshape(-1, 3, 4)
+        z = np.zeros((0, 3, 3), np.float32)
+        return Model(z, z, material, m, name or path, obj_path=path)
 
 
 @dataclass(frozen=True)

@@ -308,3 +308,33 @@ def test_environment_map_bit_exact(api, oracle_mod):
     assert_bit_equal(r.math_batch(8, y, x)[0], oracle_mod.math_batch(8, y, x)[0], "atan2")
     v = rng.uniform(-1.001, 1.001, 20000).astype(np.float32)
     assert_bit_equal(r.math_batch(9, v)[0], oracle_mod.math_batch(9, v)[0], "asin")
+
+
+def test_obj_model_renders_like_its_triangle_soup(api, oracle_mod, tmp_path):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import GGX, Model, SceneDesc
+    from test_host import OBJ_TEXT
+    path = tmp_path / "thing.obj"
+    path.write_text(OBJ_TEXT)
+    room = scenes.cornell_models()[:4]
+    sc = SceneDesc.new(room + [Model.from_obj(str(path), GGX.new_metal((0.8, 0.6, 0.2), 0.3))], scenes.reference_camera(1.5))
+    r = api.Renderer(sc, 48, 32, max_bounces=5)
+    o = oracle_mod.Oracle(sc)
+    assert_bit_equal(r.render_samples(0, 3), o.render_samples(48, 32, 3, max_bounces=5), "scene with an OBJ-loaded model")
+
+
+def test_framebuffer_is_visible_to_torch_in_place(api, cornell64):
+    """the multi-GPU gather reads libptmi's accumulation buffer through __cuda_array_interface__ (no host round trip)"""
+    import torch
+    from path_tracer_amd.dist import gather_framebuffer, wrap_device_framebuffer
+    r = api.Renderer(cornell64, 64, 64, max_bounces=3)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    acc, _, _ = r.render(0, 2)
+    ptr, n = r.accum_device_ptr()
+    assert n == 64 * 64
+    t = wrap_device_framebuffer(ptr, 64, 64, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    assert_bit_equal(t.cpu().numpy(), acc, "device view of the framebuffer")
+    assert gather_framebuffer(t, 64, 64, 0, 1, 4) is t
+    r.set_stream(None)

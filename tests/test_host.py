@@ -119,3 +119,63 @@ def test_row_sharding_partitions_the_image(api, cornell64):
         assert np.array_equal(rows, rows_of_rank(50, rank, 3, 4))
         seen.append(rows)
     assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(50))
+
+
+OBJ_TEXT = """# synthetic OBJ exercising load_obj (blas.rs:44-131)
+o thing
+v -100 -228 0
+v 100 -228 0
+v 100 -28.5 0.25
+v -100 -28.5 1e-1
+v 0 120.125 -40
+vt 0.5 0.5
+vn 0 0 2
+vn 0.0 3.0 4.0
+usemtl whatever
+g quad_with_normals
+f 1/1/1 2/1/1 3/1/2 4/1/2
+g relative_indices
+f -5//-2 -4//-1 -1//1
+g face_normal_fallback
+f 4/1/0 3/1/0 5/1/0
+s off
+f 1//1 3//1 5//1 2//2 4//2
+"""
+
+
+def test_obj_loader_matches_oracle(api, oracle_mod, tmp_path):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Lambertian, Model, SceneDesc
+    path = tmp_path / "thing.obj"
+    path.write_text(OBJ_TEXT)
+    room = scenes.cornell_models()[:4]
+    rot = np.array([[[0, 0, 1, 30.0], [0, 1, 0, 0], [-1, 0, 0, -20.0]]], np.float32)
+    sc = SceneDesc.new(room + [Model.from_obj(str(path), Lambertian.new((0.3, 0.6, 0.9)), rot)], scenes.reference_camera(1.0))
+    r = api.Renderer(sc, 32, 32)
+    o = oracle_mod.Oracle(sc)
+    gp, gn = r.model_vertices(4)
+    cp, cn = o.model_vertices(4)
+    assert gp.shape[0] == 2 + 1 + 1 + 3        # quad fan, triangle, triangle, pentagon fan
+    assert_bit_equal(gp, cp, "obj positions"); assert_bit_equal(gn, cn, "obj normals")
+    assert np.allclose(gn[0, 0], [0, 0, 1]) and np.allclose(gn[1, 2], [0, 0.6, 0.8])          # vn normalised on load
+    assert_bit_equal(gp[2], np.array([[-100, -228, 0], [100, -228, 0], [0, 120.125, -40]], np.float32), "negative indices")
+    e1, e2 = gp[3, 1] - gp[3, 0], gp[3, 2] - gp[3, 0]
+    assert np.allclose(gn[3, 0], np.cross(e1, e2)) and np.array_equal(gn[3, 0], gn[3, 2])     # un-normalised face normal
+    _cmp(r.blas_dump(4), o.blas_dump(4), "obj blas")
+    _cmp(r.tlas_dump(0), o.tlas_dump(0), "obj tlas")
+
+
+@pytest.mark.parametrize("text,code", [("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", -7), ("v 0 0 zero\n", -7), ("v 0 0 0\nf 1//1 2//1 3//1\n", -7), ("# nothing\n", -7)])
+def test_obj_loader_errors(api, tmp_path, text, code):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Lambertian, Model, SceneDesc
+    path = tmp_path / "bad.obj"
+    path.write_text(text)
+    sc = SceneDesc.new(scenes.cornell_models()[:4] + [Model.from_obj(str(path), Lambertian.new((1, 1, 1)))], scenes.reference_camera(1.0))
+    with pytest.raises(api.PtError) as e:
+        api.Renderer(sc, 8, 8)
+    assert e.value.code == code
+    sc.models[-1].obj_path = str(tmp_path / "missing.obj")
+    with pytest.raises(api.PtError) as e:
+        api.Renderer(sc, 8, 8)
+    assert e.value.code == -6

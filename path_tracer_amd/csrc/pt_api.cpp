@@ -44,6 +44,7 @@ struct pt_ctx
 
     // scene residency
     bool scene_uploaded = false;
+    DevBuf d_spill;
     DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights, d_env;
     std::vector<f4> h_env;
     uint32_t env_w = 0, env_h = 0;
@@ -195,7 +196,11 @@ int upload_scene(pt_ctx* c)
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
     const size_t blob_lds = c->lds_scene ? blob.size() : 0;
     uint32_t threads = 256;
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_entries * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
+#ifndef PT_STACK_LDS_LEVELS
+#define PT_STACK_LDS_LEVELS 14
+#endif
+    sv.stack_lds = std::min<uint32_t>(sv.stack_entries, PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -203,6 +208,13 @@ int upload_scene(pt_ctx* c)
     uint32_t per_cu = (uint32_t)std::min<size_t>((160 * 1024) / std::max<size_t>(lds, 1), 2048 / threads);
     per_cu = std::max(1u, std::min(per_cu, 8u));
     c->trace_blocks = (uint32_t)c->n_cus * per_cu;
+    sv.stack_spill = nullptr;
+    if (sv.stack_entries > sv.stack_lds)
+    {
+        const size_t lanes = (size_t)c->trace_blocks * threads;
+        if ((r = dev_alloc(c, c->d_spill, (size_t)(sv.stack_entries - sv.stack_lds) * lanes * 8))) return r;
+        sv.stack_spill = (uint64_t*)c->d_spill.p;
+    }
 
     for (uint32_t q = 0; q < Q_COUNT; ++q) c->class_present[q] = (q == Q_TERMINAL);
     for (const DInstance& in : f.instances) c->class_present[in.qclass & 0xffu] = true;
@@ -533,7 +545,7 @@ void pt_destroy(pt_ctx* c)
     {
         (void)hipStreamSynchronize(c->stream);
         for (DevBuf& b : c->pool) dev_free(b);
-        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_accum, &c->d_position, &c->d_id};
+        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_spill, &c->d_accum, &c->d_position, &c->d_id};
         for (DevBuf* b : bufs) dev_free(*b);
         if (c->h_counters) (void)hipHostFree(c->h_counters);
         for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -303,8 +303,21 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    uint2* const stack = reinterpret_cast<uint2*>(smem + blob_words) + threadIdx.x;
+    // per-lane stack of (node, t_enter): [level][thread] in LDS (conflict-free ds_read_b64); a BVH deeper than the LDS budget
+    // spills its deepest levels to global memory ([level][global lane], coalesced) so that occupancy does not collapse
+    struct LaneStack
+    {
+        uint2* lds;
+        uint2* spill;
+        uint32_t stride, lds_levels, spill_stride;
+        __device__ __forceinline__ uint2& at(uint32_t level) const
+        {
+            return level < lds_levels ? lds[level * stride] : spill[(size_t)(level - lds_levels) * spill_stride];
+        }
+    };
     const uint32_t stride = blockDim.x;
+    const LaneStack stack{reinterpret_cast<uint2*>(smem + blob_words) + threadIdx.x,
+                          reinterpret_cast<uint2*>(sv.stack_spill) + (blockIdx.x * blockDim.x + threadIdx.x), stride, sv.stack_lds, gridDim.x * blockDim.x};
     const uint32_t n = *n_ptr;
     const uint32_t prim_bits = sv.prim_bits;
 
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     WaveRange wr = first_range(n, chunk);
     // staged material binning (CLOSEST_WORLD): finished rays wait in LDS until ~4 waves' worth can be appended at once
     constexpr uint32_t kStageCap = 256;
-    uint2* const stage_idx = reinterpret_cast<uint2*>(smem + blob_words) + (size_t)sv.stack_entries * blockDim.x +
+    uint2* const stage_idx = reinterpret_cast<uint2*>(smem + blob_words) + (size_t)sv.stack_lds * blockDim.x +
                              (threadIdx.x >> 6) * kStageCap;
     uint32_t staged = 0, light_hits = 0, valid_rays = 0;
     Region bin_region[Q_COUNT];
@@ -464,7 +477,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
-                    stack[0] = make_uint2(root, 0u);
+                    stack.at(0u) = make_uint2(root, 0u);
                     sp = 1;
                     active = true;
                 }
@@ -485,7 +498,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 // TLAS::any_intersect on the world with t_max = light_t * (1 - EPS)   tlas.rs:111-144, blas.rs:257-294
                 if (sp == 0u) { active = false; pending = true; chain_code = 0u; continue; }
                 sp -= 1u;
-                const uint32_t id = stack[sp * stride].x;
+                const uint32_t id = stack.at(sp).x;
                 const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
                 float t_enter;
                 const bool hit = in_blas ? slab(n0, n1, ob.o, ob.inv, t_max, t_enter) : slab(n0, n1, w.o, w.inv, t_max, t_enter);
@@ -493,8 +506,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 const uint32_t ka = n0.w, kkind = n1.w >> NODE_KIND_SHIFT, kb = n1.w & NODE_PAYLOAD_MASK;
                 if (kkind == NODE_BRANCH)
                 {
-                    stack[sp * stride] = make_uint2(ka, 0u);
-                    stack[(sp + 1u) * stride] = make_uint2(kb, 0u);
+                    stack.at(sp) = make_uint2(ka, 0u);
+                    stack.at(sp + 1u) = make_uint2(kb, 0u);
                     sp += 2u;
                 }
                 else if (kkind == NODE_TRIS)
@@ -518,7 +531,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     ob = to_object(bl, ka, w, ray_finite, blas_root);
                     in_blas = true;
                     blas_base = sp;
-                    stack[sp * stride] = make_uint2(blas_root, 0u);
+                    stack.at(sp) = make_uint2(blas_root, 0u);
                     sp += 1u;
                 }
                 continue;
@@ -532,7 +545,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     any_phase = true;
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
-                    if (t_max == t_max) { stack[0] = make_uint2(out.world_root, 0u); sp = 1u; }
+                    if (t_max == t_max) { stack.at(0u) = make_uint2(out.world_root, 0u); sp = 1u; }
                     else { active = false; pending = true; chain_code = 0u; } // NaN t_max: every box test fails -> visible
                     continue;
                 }
@@ -541,7 +554,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 continue;
             }
             sp -= 1u;
-            const uint2 e = stack[sp * stride];
+            const uint2 e = stack.at(sp);
             if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
             const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
             const uint32_t a = nw[3];
@@ -560,12 +573,12 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 if (hl && hr)
                 {
                     const bool left_near = tl < tr;
-                    stack[sp * stride] = left_near ? make_uint2(b, asu(tr)) : make_uint2(a, asu(tl));
-                    stack[(sp + 1u) * stride] = left_near ? make_uint2(a, asu(tl)) : make_uint2(b, asu(tr));
+                    stack.at(sp) = left_near ? make_uint2(b, asu(tr)) : make_uint2(a, asu(tl));
+                    stack.at(sp + 1u) = left_near ? make_uint2(a, asu(tl)) : make_uint2(b, asu(tr));
                     sp += 2u;
                 }
-                else if (hl) { stack[sp * stride] = make_uint2(a, asu(tl)); sp += 1u; }
-                else if (hr) { stack[sp * stride] = make_uint2(b, asu(tr)); sp += 1u; }
+                else if (hl) { stack.at(sp) = make_uint2(a, asu(tl)); sp += 1u; }
+                else if (hr) { stack.at(sp) = make_uint2(b, asu(tr)); sp += 1u; }
             }
             else if (kind == NODE_TRIS)
             {
@@ -594,7 +607,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 inst = a;
                 in_blas = true;
                 blas_base = sp;
-                stack[sp * stride] = make_uint2(blas_root, 0u); // root pushed without a box test  blas.rs:217
+                stack.at(sp) = make_uint2(blas_root, 0u); // root pushed without a box test  blas.rs:217
                 sp += 1u;
             }
         }
@@ -1292,7 +1305,7 @@ size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
     const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 8 : 0; // per-wave binning stage (k_closest)
-    return blob + (size_t)tl.scene.stack_entries * tl.block_threads * (closest ? 8 : 4) + stage;
+    return blob + (closest ? (size_t)tl.scene.stack_lds * tl.block_threads * 8 : (size_t)tl.scene.stack_entries * tl.block_threads * 4) + stage;
 }
 
 } // namespace

@@ -116,7 +116,9 @@ struct SceneView
     float light_weight_sum;           // LightSampler::max                         light_sampler.rs:43
     uint32_t has_volumes;             // some material carries Some(Volume): per-path volume stacks are live
     uint32_t blob_bytes;              // nodes + tri_isect + instances, multiple of 16
-    uint32_t stack_entries;           // per-lane traversal stack capacity
+    uint32_t stack_entries;           // per-lane traversal stack capacity (exact bound)
+    uint32_t stack_lds;               // closest-hit levels kept in LDS; deeper levels spill to `stack_spill` (deep BLASes only)
+    uint64_t* stack_spill;            // 8-byte (node, t_enter) records [level - stack_lds][global lane], null when stack_entries <= stack_lds
 };
 
 struct CameraView

@@ -240,14 +240,14 @@ struct Stream
 
 // ---- shuffled-scrambled Sobol (src/sampling.rs) -------------------------------------------------------------------
 PT_HD uint32_t rev32(uint32_t x) { return __builtin_bitreverse32(x); }
-PT_HD uint32_t sobol_direction(int bit) // DIRECTIONS[bit], sampling.rs:4-8: rows of the Pascal-triangle-mod-2 matrix
+PT_HD uint32_t sobol_direction(int bit) // DIRECTIONS[bit], sampling.rs:4-8
 {
-    // v_bit = XOR over the set bits j of `bit` of pattern, equivalently: bit-reversed Sierpinski rows.
-    // Closed form: start at 0x80000000 and for each set bit j of `bit` do v ^= v >> (1 << j).
-    uint32_t v = 0x80000000u;
-    for (int j = 0; j < 5; ++j)
-        if (bit & (1 << j)) v ^= v >> (1 << j);
-    return v;
+    constexpr uint32_t kDirections[32] = {
+        0x80000000u, 0xc0000000u, 0xa0000000u, 0xf0000000u, 0x88000000u, 0xcc000000u, 0xaa000000u, 0xff000000u,
+        0x80800000u, 0xc0c00000u, 0xa0a00000u, 0xf0f00000u, 0x88880000u, 0xcccc0000u, 0xaaaa0000u, 0xffff0000u,
+        0x80008000u, 0xc000c000u, 0xa000a000u, 0xf000f000u, 0x88008800u, 0xcc00cc00u, 0xaa00aa00u, 0xff00ff00u,
+        0x80808080u, 0xc0c0c0c0u, 0xa0a0a0a0u, 0xf0f0f0f0u, 0x88888888u, 0xccccccccu, 0xaaaaaaaau, 0xffffffffu};
+    return kDirections[bit];
 }
 PT_HD uint32_t sobol_dim1(uint32_t index)                                                               // sampling.rs:24-30
 {

@@ -45,15 +45,15 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"Cornell {WIDTH}x{HEIGHT}, {spp} spp of 256, depth {DEPTH}, {threads} threads, {dt:.1f} s"}
 
 
-def _profiled_traffic():
+def _profiled_traffic(rays_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect PMC
-    counters on itself, so this is the profiled run's figure (same workload per launch), not this run's."""
+    counters on itself: the profiled bytes PER RAY (same kernel, same scene) are scaled by this run's rays per launch."""
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
-        k = d["k_closest<true, 0>"]
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": f"profiles/{files[-1]} ({k['launches']} launches at batch 43 spp)"}
+        k = json.load(open(os.path.join(ROOT, "profiles", files[-1])))["k_closest_world"]
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_ray"] * rays_per_launch,
+                "source": f"profiles/{files[-1]}: {k['hbm_bytes_per_ray']:.1f} B/ray measured over {k['rays'] / 1e6:.0f} M rays x this run's rays per launch"}
     except Exception:
         return None
 
@@ -135,13 +135,13 @@ def main():
             "config": {"workload": f"Cornell box (36 triangles, 6 BLAS) {WIDTH}x{HEIGHT}, {args.spp} spp, depth {DEPTH}, NEE+MIS",
                        "parallelism": f"rows/{world}", "mpaths_per_s": paths / dt / 1e6, "rays_per_path": rays / max(paths, 1.0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_closest<LDS,WORLD>", "avg_launch_ms": avg_ms, "launches": int(launches),
+                         "traffic": None, "kernel": "k_closest<LDS, PRIMARY|WORLD>", "avg_launch_ms": avg_ms, "launches": int(launches),
                          "algorithmic_bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": st.rays_closest / launches,
                          "closest_Mray_per_s_in_kernel": st.rays_closest / max(st.ms_trace_closest, 1e-9) / 1e3},
             "kernel_ms": {"trace_closest": st.ms_trace_closest, "trace_any": st.ms_trace_any, "trace_light": st.ms_trace_light,
                           "shade": st.ms_shade, "generate": st.ms_generate, "accumulate": st.ms_accumulate},
         }
-        tr = _profiled_traffic()
+        tr = _profiled_traffic(st.rays_closest / launches)
         if tr is not None:
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]

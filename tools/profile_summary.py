@@ -55,6 +55,21 @@ def main(src, tag):
                 traffic[k] = {"launches": launches, "read_bytes_per_launch": 2 * r["FETCH_SIZE"] * 1024 / launches,
                               "write_bytes_per_launch": r["WRITE_SIZE"] * 1024 / launches}
                 traffic[k]["hbm_bytes_per_launch"] = traffic[k]["read_bytes_per_launch"] + traffic[k]["write_bytes_per_launch"]
+    # the dominant kernel is k_closest in its two world modes (PRIMARY = bounce 0, WORLD = later bounces): bytes per traced ray
+    try:
+        bench = None
+        for ln in open(os.path.join(src, "pmc3.log")):
+            if ln.startswith("{"):
+                bench = json.loads(ln)
+        rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]
+        keys = [k for k in traffic if k.startswith("k_closest<") and (k.endswith(", 0>") or k.endswith(", 3>"))]
+        tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
+        traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays,
+                                      "note": "PMC passes at batch 43 spp; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read"}
+        lines += ["", f"Dominant kernel (k_closest, modes PRIMARY+WORLD): {tot / 1e9:.2f} GB of HBM traffic for {rays / 1e6:.1f} M rays = "
+                  f"**{tot / rays:.1f} B/ray** (algorithmic: 48 B/ray)."]
+    except Exception as e:  # noqa: BLE001
+        lines += ["", f"(bytes per ray not derived: {e})"]
     open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(lines))

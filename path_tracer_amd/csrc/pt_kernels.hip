@@ -636,12 +636,12 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
-enum { ANY_SHADOW = 0, ANY_LCHAIN = 1, ANY_HOOK = 2 };
+enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 
 template <bool LDS_SCENE, int MODE>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
-                                              const f4* __restrict__ lhit, uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid)
+                                              uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid)
 {
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
@@ -684,15 +684,6 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 w.inv = rcp3(w.d);
                 ray_finite = finite3(w.o) && finite3(w.d);
                 t_max = a.w;
-                bool go = true;
-                if (MODE == ANY_LCHAIN)
-                {
-                    // integrator.rs:100-103: only rays whose lights-TLAS closest hit exists; t_max = light_t * (1 - EPS)
-                    const f4 lh = lhit[pid];
-                    go = asu(lh.w) != MISS_ID;
-                    t_max = lh.x * (1.0f - PT_EPSILON);
-                }
-                if (go)
                 {
                     if (t_max == t_max)
                     {
@@ -1331,15 +1322,15 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
-                            const f4* lhit, uint32_t* occluded, uint32_t* n_valid)
+                            uint32_t* occluded, uint32_t* n_valid)
 {
     const size_t lds = trace_lds_bytes(tl, false);
     if (tl.lds_scene)
         hipLaunchKernelGGL((k_any<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, lhit, occluded, n_valid);
+                           n_ptr, head, occluded, n_valid);
     else
         hipLaunchKernelGGL((k_any<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, lhit, occluded, n_valid);
+                           n_ptr, head, occluded, n_valid);
 }
 
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
@@ -1370,7 +1361,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, nullptr, wb.st.occl_e, &row->valid_shadow);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, wb.st.occl_e, &row->valid_shadow);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -1447,7 +1438,7 @@ void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t ro
 void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded)
 {
     (void)n;
-    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, nullptr, occluded, nullptr);
+    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, occluded, nullptr);
 }
 void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy)
 {

@@ -44,7 +44,6 @@ PT_HD float pow5(float x) { float a = x * x; float b = a * a; return x * b; } //
 PT_HD float inv_sq(float x) { return 1.0f / (x * x); }                      // powi(-2)
 PT_HD float fma_rs(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-PT_HD f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 PT_HD f3 bc3(float a) { return f3{a, a, a}; }
 PT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 PT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -77,13 +76,6 @@ PT_HD f3 clamp_len_max(f3 v, float m)                                           
 // 3x3 by columns; rigid 3x4
 struct m33 { f3 c0, c1, c2; };
 PT_HD f3 mul(const m33& m, f3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }                    // Mat3A * Vec3A
-PT_HD f3 mul_t(const m33& m, f3 v) // transpose(m) * v with the same column-combination order as glam's
-{
-    f3 r0{m.c0.x, m.c0.y, m.c0.z}, r1{m.c1.x, m.c1.y, m.c1.z}, r2{m.c2.x, m.c2.y, m.c2.z};
-    // columns of the transpose are (c0.x,c1.x,c2.x) ...
-    f3 t0{r0.x, r1.x, r2.x}, t1{r0.y, r1.y, r2.y}, t2{r0.z, r1.z, r2.z};
-    return (t0 * v.x + t1 * v.y) + t2 * v.z;
-}
 struct xf34 { m33 m; f3 t; };
 PT_HD f3 xf_point(const xf34& a, f3 p) { return mul(a.m, p) + a.t; }                                   // transform_point3a
 PT_HD f3 xf_vector(const xf34& a, f3 v) { return mul(a.m, v); }                                        // transform_vector3a

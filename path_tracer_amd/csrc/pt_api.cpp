@@ -128,7 +128,12 @@ int normalise_config(pt_ctx* c, const pt_config* in)
 
 int ensure_device(pt_ctx* c)
 {
-    if (c->dev_ready) return PT_OK;
+    if (c->dev_ready)
+    {
+        // the caller's thread may have switched devices since (one process can hold several contexts)
+        HIPCHK(c, hipSetDevice(c->device));
+        return PT_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(c, PT_ERR_HIP, "no HIP device available (libptmi has no CPU path)");
@@ -145,7 +150,7 @@ int ensure_device(pt_ctx* c)
 
 int upload_scene(pt_ctx* c)
 {
-    if (c->scene_uploaded) return PT_OK;
+    if (c->scene_uploaded) return ensure_device(c);
     if (!c->scene.built) return fail(c, PT_ERR_STATE, "pt_build has not been called");
     int r = ensure_device(c);
     if (r) return r;

@@ -173,8 +173,9 @@ typedef struct pt_stats
     uint64_t state_bytes;            /* wavefront state + queues resident in HBM */
 } pt_stats;
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
-/* queue sizes of the LAST wavefront batch, one 16-word row per bounce: n_closest, -, n_shadow, -, n_lchain, -, -, n_lchain_hit,
- * n_shade[terminal, lambert, specular, dielectric, ggx], ... (diagnostic) */
+/* counter rows of the LAST wavefront batch, 16 words per bounce (diagnostic): [0] closest-queue slots, [2] shadow-queue slots,
+ * [4] NEE-chain slots, [6] NEE-chain rays traced, [7] of those hitting a light, [8..12] shade-queue slots (terminal, lambert,
+ * specular, dielectric, ggx), [13] closest rays traced, [14] shadow rays traced.  Slots include the holes producers return. */
 int pt_last_batch_counters(pt_ctx* ctx, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows);
 int pt_reset_stats(pt_ctx* ctx);
 

@@ -200,3 +200,55 @@ def cornell_media(width=256, height=256, level=3) -> SceneDesc:
         _model(*s2, Dielectric.new((1.0, 1.0, 1.0), 1.3, vol_sca), "sphere_scattering_core"),
     ]
     return SceneDesc.new(models, reference_camera(width / height), "cornell_media")
+
+
+def random_scene(seed, width=48, height=32, with_media=True) -> SceneDesc:
+    """Seeded stress scene for parity fuzzing: several emissive models (multi-entry light CDF), triangle soups and spheres with
+    every material kind, nested/instanced transforms that are exact rigid motions (quarter turns + integer translations),
+    optional participating media.  Only numpy's IEEE + - * / sqrt and integer RNG output are used."""
+    rng = np.random.default_rng(seed)
+
+    def soup(n, centre, spread):
+        c = np.asarray(centre, np.float64) + rng.integers(-spread, spread + 1, (n, 1, 3)).astype(np.float64)
+        return c + rng.integers(-40, 41, (n, 3, 3)).astype(np.float64) * 0.5
+
+    def quarter_turn():
+        axes = rng.permutation(3)
+        signs = rng.choice([-1.0, 1.0], 3)
+        m = np.zeros((3, 4), np.float32)
+        for r in range(3):
+            m[r, axes[r]] = signs[r]
+        if np.linalg.det(m[:, :3].astype(np.float64)) < 0:
+            m[0, :3] *= -1.0
+        m[:, 3] = rng.integers(-60, 61, 3).astype(np.float32)
+        return m
+
+    vol = [Volume.new((0.4, 0.62, 0.7), 0.1, 1.0 / 200.0, 0.6), Volume.new((0.8, 0.3, 0.2), 0.03, 0.0, 0.0), Volume.new((0, 0, 0), 0.0, 1.0 / 90.0, -0.3)]
+    palette = [
+        Lambertian.new((0.73, 0.73, 0.73)), Lambertian.new((0.65, 0.05, 0.05)), Specular.new((0.9, 0.95, 1.0)),
+        GGX.new_metal((0.9, 0.6, 0.2), float(rng.choice([0.05, 0.3, 0.8]))), GGX.new_dielectric((0.95, 0.95, 0.95), 0.25, 1.5, vol[0] if with_media else None),
+        Dielectric.new((0.95, 0.95, 0.95), 1.5, vol[1] if with_media else None), Dielectric.new((1.0, 1.0, 1.0), 1.33, vol[2] if with_media else None),
+        GGX.new_dielectric((1.0, 1.0, 1.0), 0.0, 1.4, None),
+    ]
+    models = cornell_models()[1:4]
+    # two or three lights of different size / power
+    for k in range(int(rng.integers(2, 4))):
+        x, z, s = rng.integers(-180, 181), rng.integers(-180, 181), int(rng.integers(20, 70))
+        y = 327.0 - k
+        quad = _quad((x - s, y, z - s), (x + s, y, z - s), (x + s, y, z + s), (x - s, y, z + s))
+        e = float(rng.integers(4, 30))
+        models.append(_model(quad, _flat_normals(quad, ROOM_CENTRE), Emissive.new((e, e * 0.9, e * 0.7)), f"light{k}"))
+    n_obj = int(rng.integers(3, 6))
+    for k in range(n_obj):
+        mat = palette[int(rng.integers(0, len(palette)))]
+        centre = (float(rng.integers(-160, 161)), float(rng.integers(-150, 100)), float(rng.integers(-160, 161)))
+        if rng.random() < 0.5:
+            t, n = sphere_mesh(int(rng.integers(1, 4)), centre, float(rng.integers(40, 110)))
+        else:
+            t = soup(int(rng.integers(1, 40)), centre, 60)
+            n = _flat_normals(t)
+        mats = None
+        if rng.random() < 0.5:
+            mats = np.stack([np.eye(3, 4, dtype=np.float32)] + [quarter_turn() for _ in range(int(rng.integers(1, 3)))])
+        models.append(Model.new(t.astype(np.float32), n.astype(np.float32), mat, mats, f"obj{k}"))
+    return SceneDesc.new(models, reference_camera(width / height), f"random_{seed}")

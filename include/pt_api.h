@@ -132,6 +132,22 @@ int pt_local_rows(pt_ctx* ctx, uint32_t* n_rows, uint32_t* rows, uint32_t cap);
 int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int pt_synchronize(pt_ctx* ctx);
 
+/* ---- after the path: State::update / State::render  src/state.rs:505-586, 629-667 ------------------------------ */
+/* One iteration of the reference's event loop (main.rs:179-218): the pixel loop for ONE sample (sample index = frame_index),
+ * then State::update on the device-resident accumulation texture.  last_inv_projection NULL or equal (f32 ==, state.rs:549) to
+ * the current camera's: accumulate.wgsl (acc += (rgb,1)); otherwise velocity.wgsl + compute.wgsl (temporal reprojection) with the PREVIOUS frame's
+ * (matrix * inv_projection).inverse(), column-major (main.rs:128,213-216; pt_inv_projection).  data / position / id as the
+ * reference hands them to state.update: this frame's (rgb,1), first-hit xyz|t, id history.  Single-rank contexts only. */
+int pt_frame(pt_ctx* ctx, uint32_t frame_index, const float* last_inv_projection, float* data_rgba, float* position_xyzt, uint32_t* id);
+int pt_inv_projection(pt_ctx* ctx, float out16_colmajor[16]); /* (cam.matrix * cam.inv_projection).inverse() of the current camera */
+/* State::render: GT tonemap of accumulation.rgb / accumulation.w (shader.wgsl:3-33,59-64), rgba f32, alpha 1, host buffer */
+int pt_present(pt_ctx* ctx, float* rgba);
+/* the same kernels on caller images (host pointers, row-major w*h; rgba f32, velocity 2 x f32, id u32): unit hooks */
+int pt_post_velocity(pt_ctx* ctx, uint32_t w, uint32_t h, const float* position, const float* last_inv_projection, float* velocity);
+int pt_post_reproject(pt_ctx* ctx, uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id,
+                      float* output);
+int pt_post_tonemap(pt_ctx* ctx, uint32_t w, uint32_t h, const float* accum, float* out);
+
 /* ---- unit hooks: TLAS::intersect / any_intersect  src/tlas.rs:66, 111 ------------------------------------------ */
 /* which: 0 world TLAS, 1 lights TLAS.  Host SoA in, host SoA out.  miss => inst = prim = 0xffffffff, t = +inf.
  * inst = TLAS leaf index in allocation order, prim = triangle index inside its BLAS (load order). */

@@ -54,6 +54,11 @@ def lib():
         L.pto_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
         L.pto_set_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.pto_camera_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pto_inv_projection.argtypes = [C.c_void_p, C.c_void_p]
+        L.pto_post_accumulate.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.pto_post_velocity.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pto_post_reproject.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+        L.pto_post_tonemap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_create_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.pto_primary_ray.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_render.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -179,6 +184,11 @@ class Oracle:
         self.L.pto_primary_ray(self.ctx, C.byref(cfg), pixel, sample, _p(o), _p(d))
         return o, d
 
+    def inv_projection(self):
+        m = np.zeros(16, np.float32)
+        self.L.pto_inv_projection(self.ctx, _p(m))
+        return m
+
     def create_ray(self, s, t):
         o = np.zeros(3, np.float32)
         d = np.zeros(3, np.float32)
@@ -283,3 +293,37 @@ def math_batch(fn, a, b=None):
     o0 = np.zeros_like(a); o1 = np.zeros_like(a)
     lib().pto_math_batch(fn, a.size, _p(a), _p(b), _p(o0), _p(o1))
     return o0, o1
+
+
+# ---- after the path (State::update / State::render)
+def post_accumulate(inp, accum):
+    inp = np.ascontiguousarray(inp, np.float32)
+    accum = np.ascontiguousarray(accum, np.float32).copy()
+    h, w = inp.shape[:2]
+    lib().pto_post_accumulate(w, h, _p(inp), _p(accum))
+    return accum
+
+
+def post_velocity(position, last_inv_projection):
+    position = np.ascontiguousarray(position, np.float32)
+    h, w = position.shape[:2]
+    v = np.zeros((h, w, 2), np.float32)
+    lib().pto_post_velocity(w, h, _p(position), _p(np.ascontiguousarray(last_inv_projection, np.float32)), _p(v))
+    return v
+
+
+def post_reproject(inp, accum, velocity, ident):
+    inp = np.ascontiguousarray(inp, np.float32); accum = np.ascontiguousarray(accum, np.float32)
+    velocity = np.ascontiguousarray(velocity, np.float32); ident = np.ascontiguousarray(ident, np.uint32)
+    h, w = inp.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    lib().pto_post_reproject(w, h, _p(inp), _p(accum), _p(velocity), _p(ident), _p(out))
+    return out
+
+
+def post_tonemap(accum):
+    accum = np.ascontiguousarray(accum, np.float32)
+    h, w = accum.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    lib().pto_post_tonemap(w, h, _p(accum), _p(out))
+    return out

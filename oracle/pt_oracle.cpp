@@ -1440,6 +1440,14 @@ int pto_camera_matrices(pto_ctx* c, float m34[12], float ip[16], float rm[16])
     return 0;
 }
 
+int pto_inv_projection(pto_ctx* c, float out16[16])                            // (cam.matrix * cam.inv_projection).inverse()  main.rs:128
+{
+    if (!c->camera.set) return -1;
+    M4 inv = mat4_inverse(c->camera.ray_matrix);
+    std::memcpy(out16, &inv, 64);
+    return 0;
+}
+
 int pto_create_ray(pto_ctx* c, float s, float t, float o[3], float d[3])
 {
     if (!c->camera.set) return -1;
@@ -1653,6 +1661,176 @@ int pto_triangle_dump(pto_ctx* c, int which, int blas, uint32_t prim, float out3
     std::memcpy(out36 + 12, &t.positions, 36);
     std::memcpy(out36 + 21, &t.normals, 36);
     for (int i = 30; i < 36; ++i) out36[i] = 0;
+    return 0;
+}
+
+// ====================================================================== after the path: State::update + State::render
+// Restatement of src/shaders/{accumulate,velocity,compute,shader}.wgsl as dispatched by src/state.rs:505-586,629-667.
+// WGSL leaves several things to the GPU (bilinear filter weights are fixed-point in hardware, mat*vec summation order, pow/exp
+// precision, out-of-range float->int casts): they are DEFINED here — and identically in libptmi's post kernels — as exact
+// binary32 arithmetic in the order written below, pow(x,c) = exp(c ln x) with the deterministic routines, saturating casts,
+// out-of-bounds textureLoad = 0.  The reference's own output therefore differs from this by its GPU's sampler rounding.
+namespace {
+struct Img { const float* p; int w, h; V4 at(int x, int y) const { const float* q = p + ((size_t)y * w + x) * 4; return V4{q[0], q[1], q[2], q[3]}; } };
+V4 v4add(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+V4 v4scale(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+int sat_i32(float f) { return f != f ? 0 : (f >= 2147483648.0f ? 2147483647 : (f <= -2147483648.0f ? (-2147483647 - 1) : (int)f)); }
+// textureSampleLevel(tex, linear clamp-to-edge sampler, uv, 0)
+V4 sample_bilinear(const Img& t, float u, float v)
+{
+    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    float fx0 = std::floor(x), fy0 = std::floor(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = sat_i32(fx0), y0 = sat_i32(fy0);
+    auto cl = [](int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
+    int xa = cl(x0, t.w), xb = cl(x0 < 2147483647 ? x0 + 1 : x0, t.w), ya = cl(y0, t.h), yb = cl(y0 < 2147483647 ? y0 + 1 : y0, t.h);
+    V4 top = v4add(v4scale(t.at(xa, ya), 1.0f - fx), v4scale(t.at(xb, ya), fx));
+    V4 bot = v4add(v4scale(t.at(xa, yb), 1.0f - fx), v4scale(t.at(xb, yb), fx));
+    return v4add(v4scale(top, 1.0f - fy), v4scale(bot, fy));
+}
+V3 w_divide(V4 v) { float d = v.w > 1.0f ? v.w : 1.0f; return V3{v.x / d, v.y / d, v.z / d}; } // v.xyz / max(v.w, 1.0)
+V3 rgb_to_ycocg(V3 c) { return V3{(0.25f * c.x + 0.5f * c.y) + -0.25f * c.z, (0.5f * c.x + 0.0f * c.y) + 0.5f * c.z, (0.25f * c.x + -0.5f * c.y) + -0.25f * c.z}; }   // compute.wgsl:64-71 (columns)
+V3 ycocg_to_rgb(V3 c) { return V3{(1.0f * c.x + 1.0f * c.y) + 1.0f * c.z, (1.0f * c.x + 0.0f * c.y) + -1.0f * c.z, (-1.0f * c.x + 1.0f * c.y) + -1.0f * c.z}; }       // compute.wgsl:73-80
+float fmax_w(float a, float b) { return a > b ? a : b; } // WGSL max/min on non-NaN data
+float fmin_w(float a, float b) { return a < b ? a : b; }
+V3 clip_aabb(V3 mn, V3 mx, V3 q)                                                     // compute.wgsl:82-101
+{
+    V3 p_clip = 0.5f * (mx + mn), e_clip = 0.5f * (mx - mn);
+    V3 v_clip = q - p_clip;
+    V3 v_unit{v_clip.x / e_clip.x, v_clip.y / e_clip.y, v_clip.z / e_clip.z};
+    float ma = fmax_w(std::fabs(v_unit.x), fmax_w(std::fabs(v_unit.y), std::fabs(v_unit.z)));
+    if (ma > 1.0f) return p_clip + v_clip / ma;
+    return q;
+}
+V3 sample_catmull_rom(const Img& tex, float uvx, float uvy)                            // compute.wgsl:16-62
+{
+    const float sx = (float)tex.w, sy = (float)tex.h;
+    float spx = uvx * sx + 0.5f, spy = uvy * sy + 0.5f;
+    float t1x = std::floor(spx - 0.5f) + 0.5f, t1y = std::floor(spy - 0.5f) + 0.5f;
+    float fx = spx - t1x, fy = spy - t1y;
+    auto w0 = [](float f) { return f * (-0.5f + f * (1.0f - 0.5f * f)); };
+    auto w1 = [](float f) { return 1.0f + f * f * (-2.5f + 1.5f * f); };
+    auto w2 = [](float f) { return f * (0.5f + f * (2.0f - 1.5f * f)); };
+    auto w3 = [](float f) { return f * f * (-0.5f + 0.5f * f); };
+    float w0x = w0(fx), w1x = w1(fx), w2x = w2(fx), w3x = w3(fx), w0y = w0(fy), w1y = w1(fy), w2y = w2(fy), w3y = w3(fy);
+    float w12x = w1x + w2x, w12y = w1y + w2y;
+    float o12x = w2x / (w1x + w2x), o12y = w2y / (w1y + w2y);
+    float p0x = (t1x - 1.0f) / sx, p0y = (t1y - 1.0f) / sy, p3x = (t1x + 2.0f) / sx, p3y = (t1y + 2.0f) / sy;
+    float p12x = (t1x + o12x) / sx, p12y = (t1y + o12y) / sy;
+    V3 c{0, 0, 0};
+    auto tap = [&](float u, float v, float wa, float wb) { c = c + w_divide(sample_bilinear(tex, u, v)) * wa * wb; };
+    tap(p0x, p0y, w0x, w0y); tap(p12x, p0y, w12x, w0y); tap(p3x, p0y, w3x, w0y);
+    tap(p0x, p12y, w0x, w12y); tap(p12x, p12y, w12x, w12y); tap(p3x, p12y, w3x, w12y);
+    tap(p0x, p3y, w0x, w3y); tap(p12x, p3y, w12x, w3y); tap(p3x, p3y, w3x, w3y);
+    return c;
+}
+float det_pow(float x, float c) { return det_exp(c * det_ln(x)); }
+float gt_tonemap_wgsl(float x, float p, float a, float m, float l, float c, float b)       // shader.wgsl:3-33
+{
+    float l0 = (p - m) * l / a;
+    float tt = rs_clamp((x - 0.0f) / (m - 0.0f), 0.0f, 1.0f);                                // smoothstep(0, m, x)
+    float w0 = 1.0f - tt * tt * (3.0f - 2.0f * tt);
+    float w2 = x >= m + l0 ? 1.0f : 0.0f;                                                   // step(m + l0, x)
+    float w1 = 1.0f - w0 - w2;
+    float toe = m * det_pow(x / m, c) + b;
+    float lin = m + a * (x - m);
+    float s0 = m + l0, s1 = m + a * l0, c2 = a * p / (p - s1);
+    float sh = p - (p - s1) * det_exp(-c2 * (x - s0) / p);
+    float r = (toe * w0 + lin * w1) + sh * w2;
+    return fmax_w(r, 0.0f);
+}
+} // namespace
+
+extern "C" int pto_post_accumulate(uint32_t w, uint32_t h, const float* input, float* accum)           // accumulate.wgsl:20-23
+{
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+    {
+        accum[4 * i] += input[4 * i]; accum[4 * i + 1] += input[4 * i + 1]; accum[4 * i + 2] += input[4 * i + 2]; accum[4 * i + 3] += 1.0f;
+    }
+    return 0;
+}
+
+extern "C" int pto_post_velocity(uint32_t w, uint32_t h, const float* position, const float* last_inv_proj, float* velocity) // velocity.wgsl:16-39
+{
+    const float* M = last_inv_proj; // column-major
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x)
+        {
+            const float* P = position + ((size_t)y * w + x) * 4;
+            float cu = ((float)x + 0.5f) / (float)w, cv = ((float)y + 0.5f) / (float)h;
+            V4 r;
+            float* rr = &r.x;
+            for (int i = 0; i < 4; ++i) rr[i] = ((M[i] * P[0] + M[4 + i] * P[1]) + M[8 + i] * P[2]) + M[12 + i] * 1.0f;
+            V3 d = w_divide(r);
+            float pu = d.x * 0.5f + 0.5f, pv = d.y * 0.5f + 0.5f;
+            velocity[((size_t)y * w + x) * 2] = cu - pu;
+            velocity[((size_t)y * w + x) * 2 + 1] = cv - pv;
+        }
+    return 0;
+}
+
+extern "C" int pto_post_reproject(uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id,
+                                  float* output)                                                                // compute.wgsl:103-212
+{
+    Img in{input, (int)w, (int)h}, acc{accum, (int)w, (int)h};
+    const float dx = (float)w, dy = (float)h;
+    for (int cy = 0; cy < (int)h; ++cy)
+        for (int cx = 0; cx < (int)w; ++cx)
+        {
+            V4 cur4 = in.at(cx, cy);
+            V3 current{cur4.x, cur4.y, cur4.z};
+            V3 m1{0, 0, 0}, m2{0, 0, 0};
+            float closest_depth = 1e20f;
+            int vx = 0, vy = 0;
+            int x0 = cx - 1 > 0 ? cx - 1 : 0, y0 = cy - 1 > 0 ? cy - 1 : 0;
+            int x1 = cx + 1 < (int)w - 1 ? cx + 1 : (int)w - 1, y1 = cy + 1 < (int)h - 1 ? cy + 1 : (int)h - 1;
+            int n = (x1 + 1 - x0) * (y1 + 1 - y0);
+            for (int x = x0; x <= x1; ++x)
+                for (int y = y0; y <= y1; ++y)
+                {
+                    V4 dd = in.at(x, y);
+                    V3 d = rgb_to_ycocg(V3{dd.x, dd.y, dd.z});
+                    m1 = m1 + d;
+                    m2 = m2 + d * d;
+                    if (dd.w < closest_depth) { closest_depth = dd.w; vx = x; vy = y; }
+                }
+            float cu = ((float)cx + 0.5f) / dx, cv = ((float)cy + 0.5f) / dy;
+            float pu = cu - velocity[((size_t)vy * w + vx) * 2], pv = cv - velocity[((size_t)vy * w + vx) * 2 + 1];
+            int px = sat_i32(std::floor(pu * dx)), py = sat_i32(std::floor(pv * dy));
+            bool oob = px < 0 || py < 0 || px >= (int)w || py >= (int)h;
+            uint32_t current_id = id[(size_t)cy * w + cx] & 0xffffu;
+            uint32_t old_id = oob ? 0u : ((id[(size_t)py * w + px] >> 16) & 0xffffu);
+            float* out = output + ((size_t)cy * w + cx) * 4;
+            if (current_id != old_id || oob)
+            {
+                float c0x = (float)cx / dx, c0y = (float)cy / dy, c1x = c0x + 1.0f / dx, c1y = c0y + 1.0f / dy;
+                V4 a = sample_bilinear(in, c0x, c0y), b = sample_bilinear(in, c0x, c1y), c = sample_bilinear(in, c1x, c0y), d = sample_bilinear(in, c1x, c1y);
+                V4 s = v4add(v4add(v4add(a, b), c), d);
+                out[0] = s.x / 4.0f; out[1] = s.y / 4.0f; out[2] = s.z / 4.0f; out[3] = s.w / 4.0f;
+            }
+            else
+            {
+                float fn = (float)n;
+                V3 mu = m1 / fn;
+                V3 var = m2 / fn - mu * mu;
+                V3 sigma{std::sqrt(var.x), std::sqrt(var.y), std::sqrt(var.z)};
+                V3 mn = mu - 1.0f * sigma, mx = mu + 1.0f * sigma;
+                V3 prev = sample_catmull_rom(acc, pu, pv);
+                V3 cl = ycocg_to_rgb(clip_aabb(mn, mx, rgb_to_ycocg(prev)));
+                V3 o = cl * (1.0f - 0.15f) + current * 0.15f;                              // mix(clamped, current, 0.15)
+                out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = 1.0f;
+            }
+        }
+    return 0;
+}
+
+extern "C" int pto_post_tonemap(uint32_t w, uint32_t h, const float* accum, float* out)                       // shader.wgsl:59-64
+{
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+    {
+        for (int k = 0; k < 3; ++k) out[4 * i + k] = gt_tonemap_wgsl(accum[4 * i + k] / accum[4 * i + 3], 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f);
+        out[4 * i + 3] = 1.0f;
+    }
     return 0;
 }
 

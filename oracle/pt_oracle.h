@@ -55,6 +55,7 @@ int pto_set_camera(pto_ctx*, const float eye[3], const float target[3], float fo
 int pto_set_environment(pto_ctx*, uint32_t w, uint32_t h, const float* rgb);
 int pto_camera_matrices(pto_ctx*, float cam_to_world_3x4[12], float inv_proj_4x4[16], float ray_matrix_4x4[16]);
 int pto_create_ray(pto_ctx*, float s, float t, float o[3], float d[3]);
+int pto_inv_projection(pto_ctx*, float out16_colmajor[16]);
 int pto_primary_ray(pto_ctx*, const pto_render_cfg*, uint32_t pixel, uint32_t sample, float o[3], float d[3]);
 
 int pto_render(pto_ctx*, const pto_render_cfg*, float* accum_rgba, float* position_xyzt, uint32_t* id, uint64_t* counters);
@@ -79,6 +80,13 @@ int pto_tlas_dump(pto_ctx*, int which, uint32_t* n_nodes, uint32_t* root, float*
                   uint32_t cap_nodes);
 int pto_light_cdf(pto_ctx*, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap);
 int pto_triangle_dump(pto_ctx*, int which, int blas, uint32_t prim, float out36[36]);
+
+/* after the path (State::update / State::render): accumulate.wgsl, velocity.wgsl, compute.wgsl, shader.wgsl's tonemap.
+ * All images row-major w*h; input/accum/output rgba f32, velocity 2 f32, id u32; last_inv_proj 4x4 column-major. */
+int pto_post_accumulate(uint32_t w, uint32_t h, const float* input, float* accum);
+int pto_post_velocity(uint32_t w, uint32_t h, const float* position, const float* last_inv_proj, float* velocity);
+int pto_post_reproject(uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id, float* output);
+int pto_post_tonemap(uint32_t w, uint32_t h, const float* accum, float* out);
 
 /* math / sampler hooks for known-answer and device-math parity tests */
 void pto_ss_sobol_raw(uint32_t n_points, uint32_t index, uint32_t seed, uint32_t out_shuffled_x_y[3]);

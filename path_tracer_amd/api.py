@@ -29,7 +29,7 @@ DEFAULT_SEED = 0x5EED5EED
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
-    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_trace_closest", "pt_trace_any",
+    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
 ]
@@ -105,6 +105,12 @@ def lib():
         L.pt_local_rows.argtypes = [vp, C.POINTER(u32), vp, u32]
         L.pt_set_stream.argtypes = [vp, vp]
         L.pt_synchronize.argtypes = [vp]
+        L.pt_frame.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.pt_inv_projection.argtypes = [vp, vp]
+        L.pt_present.argtypes = [vp, vp]
+        L.pt_post_velocity.argtypes = [vp, u32, u32, vp, vp, vp]
+        L.pt_post_reproject.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
+        L.pt_post_tonemap.argtypes = [vp, u32, u32, vp, vp]
         L.pt_trace_closest.argtypes = [vp, C.c_int, u32] + [vp] * 8
         L.pt_trace_any.argtypes = [vp, C.c_int, u32] + [vp] * 4
         L.pt_ss_sobol.argtypes = [vp, u32, u32, vp, vp, vp]
@@ -260,6 +266,52 @@ class Renderer:
         n = C.c_uint64()
         self._chk(self.L.pt_accum_device_ptr(self.ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # ---- after the path: State::update / State::render
+    def inv_projection(self):
+        m = np.zeros(16, np.float32)
+        self._chk(self.L.pt_inv_projection(self.ctx, _p(m)))
+        return m
+
+    def frame(self, frame_index, last_inv_projection=None, ident=None, download=True):
+        """one event-loop iteration (main.rs:179-218): 1 spp pixel loop + State::update; returns data, position, id
+        (download=False keeps everything on the device: the id history then lives in the library's own texture)"""
+        m = None if last_inv_projection is None else np.ascontiguousarray(last_inv_projection, np.float32)
+        if not download:
+            self._chk(self.L.pt_frame(self.ctx, frame_index, _p(m), None, None, None))
+            return None
+        h, w = self.cfg.height, self.cfg.width
+        data = np.zeros((h, w, 4), np.float32); pos = np.zeros((h, w, 4), np.float32)
+        idb = np.zeros((h, w), np.uint32) if ident is None else ident
+        self._chk(self.L.pt_frame(self.ctx, frame_index, _p(m), _p(data), _p(pos), _p(idb)))
+        return data, pos, idb
+
+    def present(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), np.float32)
+        self._chk(self.L.pt_present(self.ctx, _p(out)))
+        return out
+
+    def post_velocity(self, position, last_inv_projection):
+        position = np.ascontiguousarray(position, np.float32)
+        h, w = position.shape[:2]
+        v = np.zeros((h, w, 2), np.float32)
+        self._chk(self.L.pt_post_velocity(self.ctx, w, h, _p(position), _p(np.ascontiguousarray(last_inv_projection, np.float32)), _p(v)))
+        return v
+
+    def post_reproject(self, inp, accum, velocity, ident):
+        inp = np.ascontiguousarray(inp, np.float32); accum = np.ascontiguousarray(accum, np.float32)
+        velocity = np.ascontiguousarray(velocity, np.float32); ident = np.ascontiguousarray(ident, np.uint32)
+        h, w = inp.shape[:2]
+        out = np.zeros((h, w, 4), np.float32)
+        self._chk(self.L.pt_post_reproject(self.ctx, w, h, _p(inp), _p(accum), _p(velocity), _p(ident), _p(out)))
+        return out
+
+    def post_tonemap(self, accum):
+        accum = np.ascontiguousarray(accum, np.float32)
+        h, w = accum.shape[:2]
+        out = np.zeros((h, w, 4), np.float32)
+        self._chk(self.L.pt_post_tonemap(self.ctx, w, h, _p(accum), _p(out)))
+        return out
 
     # ---- unit hooks
     def trace_closest(self, o, d, tmax=None, which=0):

@@ -58,6 +58,7 @@ struct pt_ctx
     std::vector<uint32_t> rows; // local row -> global row
     uint32_t local_pixels = 0;
     DevBuf d_accum, d_position, d_id;
+    DevBuf d_input, d_velocity, d_output; // State::update textures (pt_frame)
 
     // wavefront
     size_t cap_paths = 0, cap_slots = 0, cap_slots_term = 0;
@@ -370,7 +371,7 @@ void harvest_events(pt_ctx* c)
 }
 
 // one wavefront batch: samples [first, first+count) of every local pixel
-int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out)
+int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples = false)
 {
     const pt_config& g = c->cfg;
     RenderParams rp{};
@@ -446,11 +447,16 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, last_row - 1); }
         { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
     }
-    if (samples_out) launch_store_samples(s, rp, wb, samples_out);
+    if (samples_out)
+    {
+        launch_store_samples(s, rp, wb, samples_out);
+        // pt_frame: the frame's own colour goes to the input texture, position / id history are still updated
+        if (aux_with_samples) launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, 1u, 0u);
+    }
     else
     {
         Timer t(c, T_ACCUM);
-        launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u);
+        launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -550,7 +556,7 @@ void pt_destroy(pt_ctx* c)
     {
         (void)hipStreamSynchronize(c->stream);
         for (DevBuf& b : c->pool) dev_free(b);
-        DevBuf* bufs[] = {&c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_spill, &c->d_accum, &c->d_position, &c->d_id};
+        DevBuf* bufs[] = {&c->d_input, &c->d_velocity, &c->d_output, &c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_spill, &c->d_accum, &c->d_position, &c->d_id};
         for (DevBuf* b : bufs) dev_free(*b);
         if (c->h_counters) (void)hipHostFree(c->h_counters);
         for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -774,6 +780,137 @@ int pt_synchronize(pt_ctx* c)
     if (!c) return PT_ERR_ARG;
     if (!c->dev_ready) return PT_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// ---- after the path: State::update / State::render
+int pt_inv_projection(pt_ctx* c, float out16[16])
+{
+    if (!c || !out16) return PT_ERR_ARG;
+    if (!c->scene.camera.set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
+    c->scene.inv_projection(out16);
+    return PT_OK;
+}
+
+int pt_frame(pt_ctx* c, uint32_t frame_index, const float* last_inv_projection, float* data, float* position, uint32_t* id)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = precheck(c))) return r;
+    if (c->cfg.world_size != 1) return fail(c, PT_ERR_STATE, "pt_frame needs the whole frame on one rank (3x3 neighbourhoods cross row strips)");
+    if ((r = upload_scene(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t px = c->local_pixels;
+    if ((r = dev_alloc(c, c->d_input, px * 16)) || (r = dev_alloc(c, c->d_velocity, px * 8)) || (r = dev_alloc(c, c->d_output, px * 16))) return r;
+    if (id) HIPCHK(c, hipMemcpyAsync(c->d_id.p, id, px * 4, hipMemcpyHostToDevice, c->stream));
+    if ((r = ensure_wavefront(c, px, c->cfg.max_bounces + 2))) return r;
+    if ((r = run_batch(c, frame_index, 1, true, (f4*)c->d_input.p, true))) return r;   // main.rs:181-207, one sample per pixel
+    hipStream_t s = c->stream;
+    const int w = (int)c->cfg.width, h = (int)c->cfg.height;
+    bool moved = false;                                                                                                    // state.rs:549 `inv_projection == last_inv_projection`
+    if (last_inv_projection)
+    {
+        float cur[16];
+        c->scene.inv_projection(cur);
+        for (int i = 0; i < 16; ++i) moved |= !(cur[i] == last_inv_projection[i]);
+    }
+    if (!moved) launch_post_accumulate(s, (uint32_t)px, (const f4*)c->d_input.p, (f4*)c->d_accum.p);           // state.rs:561-566
+    else
+    {
+        launch_post_velocity(s, w, h, (const f4*)c->d_position.p, last_inv_projection, (float*)c->d_velocity.p);            // state.rs:569-572
+        launch_post_reproject(s, w, h, (const f4*)c->d_input.p, (const f4*)c->d_accum.p, (const float*)c->d_velocity.p,
+                              (const uint32_t*)c->d_id.p, (f4*)c->d_output.p);                                              // state.rs:574-578
+        HIPCHK(c, hipMemcpyAsync(c->d_accum.p, c->d_output.p, px * 16, hipMemcpyDeviceToDevice, s));                        // state.rs:583
+    }
+    if (data) HIPCHK(c, hipMemcpyAsync(data, c->d_input.p, px * 16, hipMemcpyDeviceToHost, s));
+    if (position) HIPCHK(c, hipMemcpyAsync(position, c->d_position.p, px * 16, hipMemcpyDeviceToHost, s));
+    if (id) HIPCHK(c, hipMemcpyAsync(id, c->d_id.p, px * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_present(pt_ctx* c, float* rgba)
+{
+    if (!c || !rgba) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t px = c->local_pixels;
+    if ((r = dev_alloc(c, c->d_output, px * 16))) return r;
+    launch_post_tonemap(c->stream, (uint32_t)px, (const f4*)c->d_accum.p, (f4*)c->d_output.p);
+    HIPCHK(c, hipMemcpyAsync(rgba, c->d_output.p, px * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+namespace {
+struct TmpBufs
+{
+    std::vector<DevBuf> b;
+    ~TmpBufs() { for (DevBuf& x : b) dev_free(x); }
+    int up(pt_ctx* c, const void* src, size_t bytes, void** out)
+    {
+        DevBuf d;
+        int r = dev_alloc(c, d, bytes);
+        if (r) return r;
+        b.push_back(d);
+        if (src) { hipError_t e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice); if (e != hipSuccess) return fail(c, PT_ERR_HIP, hipGetErrorString(e)); }
+        *out = d.p;
+        return PT_OK;
+    }
+};
+} // namespace
+
+int pt_post_velocity(pt_ctx* c, uint32_t w, uint32_t h, const float* position, const float* last_inv_projection, float* velocity)
+{
+    if (!c || !position || !last_inv_projection || !velocity || !w || !h) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    TmpBufs t;
+    void *dp, *dv;
+    const size_t px = (size_t)w * h;
+    if ((r = t.up(c, position, px * 16, &dp)) || (r = t.up(c, nullptr, px * 8, &dv))) return r;
+    launch_post_velocity(c->stream, (int)w, (int)h, (const f4*)dp, last_inv_projection, (float*)dv);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(velocity, dv, px * 8, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_post_reproject(pt_ctx* c, uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id, float* output)
+{
+    if (!c || !input || !accum || !velocity || !id || !output || !w || !h) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    TmpBufs t;
+    void *di, *da, *dv, *did, *dout;
+    const size_t px = (size_t)w * h;
+    if ((r = t.up(c, input, px * 16, &di)) || (r = t.up(c, accum, px * 16, &da)) || (r = t.up(c, velocity, px * 8, &dv)) ||
+        (r = t.up(c, id, px * 4, &did)) || (r = t.up(c, nullptr, px * 16, &dout)))
+        return r;
+    launch_post_reproject(c->stream, (int)w, (int)h, (const f4*)di, (const f4*)da, (const float*)dv, (const uint32_t*)did, (f4*)dout);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(output, dout, px * 16, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_post_tonemap(pt_ctx* c, uint32_t w, uint32_t h, const float* accum, float* out)
+{
+    if (!c || !accum || !out || !w || !h) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    TmpBufs t;
+    void *da, *dout;
+    const size_t px = (size_t)w * h;
+    if ((r = t.up(c, accum, px * 16, &da)) || (r = t.up(c, nullptr, px * 16, &dout))) return r;
+    launch_post_tonemap(c->stream, (uint32_t)px, (const f4*)da, (f4*)dout);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, px * 16, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -41,8 +41,14 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
                   uint32_t grid_blocks, const CameraView& cam, const EnvView& env);
 // accum[pixel] += sum over batch samples in order of (finalised rgb, 1); position/id of the last samples
 void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
-                       uint32_t write_position);
+                       uint32_t write_position, uint32_t add_to_accum);
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out);
+
+// after the path (pt_post.hip)
+void launch_post_accumulate(hipStream_t s, uint32_t n, const f4* input, f4* accum);
+void launch_post_velocity(hipStream_t s, int w, int h, const f4* position, const float* m16, float* velocity_xy);
+void launch_post_reproject(hipStream_t s, int w, int h, const f4* input, const f4* accum, const float* velocity_xy, const uint32_t* id, f4* output);
+void launch_post_tonemap(hipStream_t s, uint32_t n, const f4* accum, f4* out);
 
 // unit hooks
 void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits);

@@ -1215,7 +1215,7 @@ __device__ __forceinline__ f3 finalise(f3 acc)
 
 // accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206
 __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const PathState st, f4* accum, f4* position, uint32_t* id,
-                                                     const uint32_t write_position)
+                                                     const uint32_t write_position, const uint32_t add_to_accum)
 {
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= rp.local_pixels) return;
@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
         // (id << 16) | new once per sample: only the last two samples survive in 32 bits
         if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
     }
-    accum[lp] = a;
+    if (add_to_accum) accum[lp] = a;
     id[lp] = idv;
     if (write_position) position[lp] = st.first_pos[(rp.batch_samples - 1u) * rp.local_pixels + lp];
 }
@@ -1416,10 +1416,10 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
 }
 
 void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
-                       uint32_t write_position)
+                       uint32_t write_position, uint32_t add_to_accum)
 {
     const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, wb.st, accum, position, id, write_position);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, wb.st, accum, position, id, write_position, add_to_accum);
 }
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)
 {

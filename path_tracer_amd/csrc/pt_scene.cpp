@@ -617,6 +617,8 @@ void HostScene::set_camera(const float eye_[3], const float target_[3], float fo
     camera.set = true;
 }
 
+void HostScene::inv_projection(float out16[16]) const { mat4_inverse(camera.ray_matrix, out16); }
+
 void HostScene::create_ray(float s, float t, float o[3], float d[3]) const                // Camera::create_ray  camera.rs:94-105
 {
     const float* M = camera.ray_matrix;

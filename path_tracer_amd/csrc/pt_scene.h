@@ -106,6 +106,7 @@ public:
     int build(std::string* err);
     void set_camera(const float eye[3], const float target[3], float fov_deg, float aspect);
     void create_ray(float s, float t, float o[3], float d[3]) const;
+    void inv_projection(float out16[16]) const; // (matrix * inv_projection).inverse()  main.rs:128
 
 private:
     void build_blas(HostBlas& out, const HostModel& m);

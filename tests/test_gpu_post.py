@@ -1,0 +1,125 @@
+"""GPU (-m gpu): the post-kernels (State::update / State::render, src/state.rs:505-586,629-667) through the C-ABI against the
+oracle's restatement.  Bit-exact; a NaN is a NaN whatever its payload (x86 and gfx950 differ in the default NaN's sign)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _canon(a):
+    a = np.array(a, np.float32, copy=True)
+    a[np.isnan(a)] = np.float32(np.nan)
+    return a
+
+
+def assert_same(a, b, what):
+    assert_bit_equal(_canon(a), _canon(b), what)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from path_tracer_amd import api
+    api.lib()
+    return api
+
+
+@pytest.fixture(scope="module")
+def rnd(api, cornell64):
+    return api.Renderer(cornell64, 64, 64, max_bounces=4)
+
+
+def _moved(cam, dx):
+    from path_tracer_amd.scene_desc import Camera
+    return Camera.new((cam.origin[0] + dx, cam.origin[1], cam.origin[2] - 2 * dx), (cam.target[0] + 0.3 * dx, cam.target[1], cam.target[2]),
+                      cam.fov, cam.aspect_ratio)
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (37, 19), (1, 1), (256, 3)])
+def test_tonemap_kernel(rnd, oracle_mod, w, h):
+    rng = np.random.default_rng(w * 131 + h)
+    acc = (rng.uniform(0, 3, (h, w, 4)) * np.exp(rng.uniform(-6, 4, (h, w, 1)))).astype(np.float32)
+    acc[..., 3] = rng.integers(1, 300, (h, w))
+    if w > 8:
+        acc[0, 0] = [0, 0, 0, 1]; acc[0, 1] = [0, 0, 0, 0]; acc[0, 2] = [1e30, 5, 0.22, 1]; acc[0, 3] = [np.inf, -1, 0.62, 1]
+    assert_same(rnd.post_tonemap(acc), oracle_mod.post_tonemap(acc), "tonemap")
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (37, 19), (1, 1)])
+def test_velocity_kernel(rnd, oracle_mod, w, h):
+    rng = np.random.default_rng(w + 7 * h)
+    pos = rng.uniform(-600, 600, (h, w, 4)).astype(np.float32)
+    pos[..., 3] = rng.uniform(0, 2000, (h, w))
+    if w > 8:
+        pos[0, 0, :3] = np.inf; pos[0, 1, :3] = 0; pos[0, 2, :3] = [0, 50, 1000]                 # miss sentinel, origin, the eye itself
+    M = rnd.inv_projection()
+    assert_bit_equal(M, oracle_mod.Oracle(rnd.desc).inv_projection(), "inv_projection")
+    assert_same(rnd.post_velocity(pos, M), oracle_mod.post_velocity(pos, M), "velocity")
+    M2 = rng.normal(size=16).astype(np.float32)
+    assert_same(rnd.post_velocity(pos, M2), oracle_mod.post_velocity(pos, M2), "velocity, arbitrary matrix")
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 64, 0), (37, 19, 1), (1, 1, 2), (2, 5, 3), (128, 96, 4)])
+def test_reproject_kernel_on_random_images(rnd, oracle_mod, w, h, seed):
+    """all branches: history kept (same id, on-screen), id mismatch, off-screen history, velocity read at the closest-depth texel"""
+    rng = np.random.default_rng(seed)
+    inp = rng.uniform(0, 2, (h, w, 4)).astype(np.float32)
+    inp[..., 3] = rng.choice(np.array([1.0, 0.5, 2.0], np.float32), (h, w))                       # .a drives the closest-depth pick
+    acc = (rng.uniform(0, 2, (h, w, 4)) * rng.integers(1, 50, (h, w, 1))).astype(np.float32)
+    acc[..., 3] = rng.choice(np.array([0.25, 1.0, 7.0, 120.0], np.float32), (h, w))               # both sides of max(w, 1)
+    vel = (rng.normal(size=(h, w, 2)) * rng.choice([0.0, 0.01, 0.2, 1.5], (h, w, 1))).astype(np.float32)
+    new = rng.integers(0, 3, (h, w)).astype(np.uint32); old = rng.integers(0, 3, (h, w)).astype(np.uint32)
+    ident = (old << 16) | new
+    got = rnd.post_reproject(inp, acc, vel, ident); want = oracle_mod.post_reproject(inp, acc, vel, ident)
+    assert_same(got, want, "reproject")
+    if w * h > 100:
+        assert 0.05 < (want[..., 3] == 1).mean() and (want[..., 3] != 1).any()                    # both branches were taken
+
+
+def test_reproject_kernel_extreme_velocities(rnd, oracle_mod):
+    h, w = 16, 16
+    rng = np.random.default_rng(9)
+    inp = rng.uniform(0, 1, (h, w, 4)).astype(np.float32); acc = rng.uniform(0, 5, (h, w, 4)).astype(np.float32)
+    vel = np.zeros((h, w, 2), np.float32)
+    vel[0, :4] = [[np.inf, 0], [-np.inf, 0], [np.nan, 0], [1e30, -1e30]]
+    vel[1, :3] = [[-3e9, 0], [0, 3e9], [1e-30, -1e-30]]
+    ident = np.full((h, w), (1 << 16) | 1, np.uint32)
+    assert_same(rnd.post_reproject(inp, acc, vel, ident), oracle_mod.post_reproject(inp, acc, vel, ident), "extreme velocities")
+
+
+def test_frame_sequence_static_then_moving_camera(api, oracle_mod, cornell64):
+    """the reference's event loop (main.rs:179-218) for six frames: three with the camera at rest (accumulate.wgsl), then three
+    with it moving (velocity.wgsl + compute.wgsl), then State::render's tonemap — every texture after every frame"""
+    W = H = 64
+    r = api.Renderer(cornell64, W, H, max_bounces=4)
+    o = oracle_mod.Oracle(cornell64)
+    cams = [cornell64.camera] * 3 + [_moved(cornell64.camera, d) for d in (8.0, 20.0, 20.0)]
+    acc = np.zeros((H, W, 4), np.float32)
+    id_g = np.zeros((H, W), np.uint32); id_o = np.zeros((H, W), np.uint32)
+    last_g = r.inv_projection(); last_o = o.inv_projection()
+    branches = []
+    for k, cam in enumerate(cams):
+        r.set_camera(cam); o.set_camera(cam)
+        data_g, pos_g, id_g = r.frame(k, last_g, id_g)
+        data_o, pos_o, id_o, _ = o.render(W, H, 1, first_sample=k, max_bounces=4, ident=id_o)
+        assert_bit_equal(data_g, data_o, f"frame {k} data"); assert_bit_equal(pos_g, pos_o, f"frame {k} position")
+        assert_bit_equal(id_g, id_o, f"frame {k} id")
+        cur_o = o.inv_projection()
+        if np.array_equal(cur_o, last_o):
+            acc = oracle_mod.post_accumulate(data_o, acc); branches.append("accumulate")
+        else:
+            acc = oracle_mod.post_reproject(data_o, acc, oracle_mod.post_velocity(pos_o, last_o), id_o); branches.append("reproject")
+        assert_same(r.read_accumulation(), acc, f"frame {k} accumulation ({branches[-1]})")
+        last_g = r.inv_projection(); last_o = cur_o
+        assert_bit_equal(last_g, last_o, "inv_projection")
+    assert branches == ["accumulate"] * 3 + ["reproject"] * 2 + ["accumulate"]
+    assert_same(r.present(), oracle_mod.post_tonemap(acc), "present")
+    assert np.isfinite(r.present()).all()
+
+
+def test_frame_needs_the_whole_image_on_one_rank(api, cornell64):
+    r = api.Renderer(cornell64, 64, 64, rank=0, world_size=2)
+    with pytest.raises(api.PtError) as e:
+        r.frame(0)
+    assert e.value.code == -3

@@ -25,7 +25,7 @@ enum pt_status
     PT_ERR_STATE = -3,    /* call order (render before build, no camera, NEE without lights ...) */
     PT_ERR_NONRIGID = -4, /* model matrix carries scale: model.rs:40-44 asserts scale == (1,1,1) */
     PT_ERR_LIMIT = -5,    /* scene exceeds a packing limit of the device layout */
-    PT_ERR_IO = -6,       /* file cannot be read */
+    PT_ERR_IO = -6,       /* file cannot be read / written */
     PT_ERR_PARSE = -7     /* malformed OBJ (the reference panics) */
 };
 
@@ -142,11 +142,17 @@ int pt_frame(pt_ctx* ctx, uint32_t frame_index, const float* last_inv_projection
 int pt_inv_projection(pt_ctx* ctx, float out16_colmajor[16]); /* (cam.matrix * cam.inv_projection).inverse() of the current camera */
 /* State::render: GT tonemap of accumulation.rgb / accumulation.w (shader.wgsl:3-33,59-64), rgba f32, alpha 1, host buffer */
 int pt_present(pt_ctx* ctx, float* rgba);
+/* ImageHelper::write_image (src/image_helper.rs:37-58): accumulation.rgb / accumulation.w through tonemapping.rs's GT curve,
+ * gamma 1/2.2, x255, Rust `as u8`; W*H*3 bytes in framebuffer row order.  pt_write_image also encodes them as an 8-bit RGB PNG
+ * (image::save_buffer(.., ColorType::Rgb8)); an unwritable path returns PT_ERR_IO. */
+int pt_present_rgb8(pt_ctx* ctx, uint8_t* rgb);
+int pt_write_image(pt_ctx* ctx, const char* path);
 /* the same kernels on caller images (host pointers, row-major w*h; rgba f32, velocity 2 x f32, id u32): unit hooks */
 int pt_post_velocity(pt_ctx* ctx, uint32_t w, uint32_t h, const float* position, const float* last_inv_projection, float* velocity);
 int pt_post_reproject(pt_ctx* ctx, uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id,
                       float* output);
 int pt_post_tonemap(pt_ctx* ctx, uint32_t w, uint32_t h, const float* accum, float* out);
+int pt_post_rgb8(pt_ctx* ctx, uint32_t w, uint32_t h, const float* accum, uint8_t* rgb);
 
 /* ---- unit hooks: TLAS::intersect / any_intersect  src/tlas.rs:66, 111 ------------------------------------------ */
 /* which: 0 world TLAS, 1 lights TLAS.  Host SoA in, host SoA out.  miss => inst = prim = 0xffffffff, t = +inf.

@@ -59,6 +59,7 @@ def lib():
         L.pto_post_velocity.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_post_reproject.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
         L.pto_post_tonemap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.pto_post_rgb8.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_create_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.pto_primary_ray.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_render.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -326,4 +327,12 @@ def post_tonemap(accum):
     h, w = accum.shape[:2]
     out = np.zeros((h, w, 4), np.float32)
     lib().pto_post_tonemap(w, h, _p(accum), _p(out))
+    return out
+
+
+def post_rgb8(accum):
+    accum = np.ascontiguousarray(accum, np.float32)
+    h, w = accum.shape[:2]
+    out = np.zeros((h, w, 3), np.uint8)
+    lib().pto_post_rgb8(w, h, _p(accum), _p(out))
     return out

@@ -1741,6 +1741,44 @@ float gt_tonemap_wgsl(float x, float p, float a, float m, float l, float c, floa
 }
 } // namespace
 
+namespace {
+float gt_tonemap_rs(float x, float p, float a, float m, float l, float c, float b)          // tonemapping.rs:66-96
+{
+    if (x < 0.0f) return b;
+    float l0 = (p - m) * l / a;
+    auto smoothstep = [](float x, float e0, float e1) {                                       // :36-52
+        if (x < e0) return 0.0f;
+        if (x > e1) return 1.0f;
+        float q = (x - e0) / (e1 - e0), r = 3.0f - 2.0f * q;
+        return q * q * r;
+    };
+    auto lerp = [](float x, float e0, float e1) {                                             // :20-34
+        if (x < e0) return 0.0f;
+        if (x > e1) return 1.0f;
+        return (x - e0) / (e1 - e0);
+    };
+    float w0 = 1.0f - smoothstep(x, 0.0f, m);
+    float w2 = lerp(x, m + l0, m + l0);
+    float w1 = 1.0f - w0 - w2;
+    float t = (m * det_pow(x / m, c) + b) * w0;                                               // gt_toe :5
+    float u = (m + a * (x - m)) * w1;                                                         // gt_linear :2
+    float s0 = m + l0, s1 = m + a * l0, c2 = a * p / (p - s1);
+    float v = (p - (p - s1) * det_exp(-c2 * (x - s0) / p)) * w2;                              // gt_shoulder :8-16
+    return t + u + v;
+}
+uint8_t as_u8(float f) { return f != f ? 0 : (f >= 255.0f ? 255 : (f <= 0.0f ? 0 : (uint8_t)f)); } // Rust `as u8`
+} // namespace
+
+// ImageHelper::write_image's byte conversion (image_helper.rs:41-48) applied to accumulation.rgb / accumulation.w
+extern "C" int pto_post_rgb8(uint32_t w, uint32_t h, const float* accum, uint8_t* out)
+{
+    const float g = 1.0f / 2.2f;
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        for (int k = 0; k < 3; ++k)
+            out[3 * i + k] = as_u8(det_pow(gt_tonemap_rs(accum[4 * i + k] / accum[4 * i + 3], 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f), g) * 255.0f);
+    return 0;
+}
+
 extern "C" int pto_post_accumulate(uint32_t w, uint32_t h, const float* input, float* accum)           // accumulate.wgsl:20-23
 {
     for (size_t i = 0; i < (size_t)w * h; ++i)

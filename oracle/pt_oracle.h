@@ -87,6 +87,7 @@ int pto_post_accumulate(uint32_t w, uint32_t h, const float* input, float* accum
 int pto_post_velocity(uint32_t w, uint32_t h, const float* position, const float* last_inv_proj, float* velocity);
 int pto_post_reproject(uint32_t w, uint32_t h, const float* input, const float* accum, const float* velocity, const uint32_t* id, float* output);
 int pto_post_tonemap(uint32_t w, uint32_t h, const float* accum, float* out);
+int pto_post_rgb8(uint32_t w, uint32_t h, const float* accum, uint8_t* out_rgb);   /* image_helper.rs:41-48, tonemapping.rs */
 
 /* math / sampler hooks for known-answer and device-math parity tests */
 void pto_ss_sobol_raw(uint32_t n_points, uint32_t index, uint32_t seed, uint32_t out_shuffled_x_y[3]);

@@ -29,7 +29,7 @@ DEFAULT_SEED = 0x5EED5EED
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
-    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_trace_closest", "pt_trace_any",
+    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
 ]
@@ -111,6 +111,9 @@ def lib():
         L.pt_post_velocity.argtypes = [vp, u32, u32, vp, vp, vp]
         L.pt_post_reproject.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
         L.pt_post_tonemap.argtypes = [vp, u32, u32, vp, vp]
+        L.pt_post_rgb8.argtypes = [vp, u32, u32, vp, vp]
+        L.pt_present_rgb8.argtypes = [vp, vp]
+        L.pt_write_image.argtypes = [vp, C.c_char_p]
         L.pt_trace_closest.argtypes = [vp, C.c_int, u32] + [vp] * 8
         L.pt_trace_any.argtypes = [vp, C.c_int, u32] + [vp] * 4
         L.pt_ss_sobol.argtypes = [vp, u32, u32, vp, vp, vp]
@@ -289,6 +292,21 @@ class Renderer:
     def present(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), np.float32)
         self._chk(self.L.pt_present(self.ctx, _p(out)))
+        return out
+
+    def present_rgb8(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 3), np.uint8)
+        self._chk(self.L.pt_present_rgb8(self.ctx, _p(out)))
+        return out
+
+    def write_image(self, path):
+        self._chk(self.L.pt_write_image(self.ctx, str(path).encode()))
+
+    def post_rgb8(self, accum):
+        accum = np.ascontiguousarray(accum, np.float32)
+        h, w = accum.shape[:2]
+        out = np.zeros((h, w, 3), np.uint8)
+        self._chk(self.L.pt_post_rgb8(self.ctx, w, h, _p(accum), _p(out)))
         return out
 
     def post_velocity(self, position, last_inv_projection):

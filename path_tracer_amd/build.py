@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libptmi.so")
-_SOURCES = ["pt_api.cpp", "pt_scene.cpp", "pt_kernels.hip", "pt_post.hip", "pt_math.h", "pt_types.h", "pt_scene.h", "pt_kernels.h", "pt_materials.h", "Makefile"]
+_SOURCES = ["pt_api.cpp", "pt_scene.cpp", "pt_kernels.hip", "pt_post.hip", "pt_png.cpp", "pt_png.h", "pt_math.h", "pt_types.h", "pt_scene.h", "pt_kernels.h", "pt_materials.h", "Makefile"]
 
 
 def is_stale() -> bool:

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "pt_kernels.h"
+#include "pt_png.h"
 #include "pt_scene.h"
 
 using namespace pt;
@@ -846,6 +847,44 @@ int pt_present(pt_ctx* c, float* rgba)
     return PT_OK;
 }
 
+static int present_rgb8_locked(pt_ctx* c, std::vector<uint8_t>& host)
+{
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t px = c->local_pixels;
+    if ((r = dev_alloc(c, c->d_output, px * 16))) return r;
+    launch_post_rgb8(c->stream, (uint32_t)px, (const f4*)c->d_accum.p, (uint8_t*)c->d_output.p);
+    host.resize(px * 3);
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->d_output.p, px * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_present_rgb8(pt_ctx* c, uint8_t* rgb)
+{
+    if (!c || !rgb) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::vector<uint8_t> host;
+    int r = present_rgb8_locked(c, host);
+    if (r) return r;
+    std::memcpy(rgb, host.data(), host.size());
+    return PT_OK;
+}
+
+int pt_write_image(pt_ctx* c, const char* path)
+{
+    if (!c || !path) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->cfg.world_size != 1) return fail(c, PT_ERR_STATE, "pt_write_image needs the whole frame on one rank (gather first)");
+    std::vector<uint8_t> host;
+    int r = present_rgb8_locked(c, host);
+    if (r) return r;
+    std::string err;
+    if (!write_png_rgb8(path, host.data(), c->cfg.width, c->cfg.height, &err)) return fail(c, PT_ERR_IO, err.c_str());
+    return PT_OK;
+}
+
 namespace {
 struct TmpBufs
 {
@@ -911,6 +950,22 @@ int pt_post_tonemap(pt_ctx* c, uint32_t w, uint32_t h, const float* accum, float
     launch_post_tonemap(c->stream, (uint32_t)px, (const f4*)da, (f4*)dout);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout, px * 16, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_post_rgb8(pt_ctx* c, uint32_t w, uint32_t h, const float* accum, uint8_t* rgb)
+{
+    if (!c || !accum || !rgb || !w || !h) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    TmpBufs t;
+    void *da, *dout;
+    const size_t px = (size_t)w * h;
+    if ((r = t.up(c, accum, px * 16, &da)) || (r = t.up(c, nullptr, px * 3, &dout))) return r;
+    launch_post_rgb8(c->stream, (uint32_t)px, (const f4*)da, (uint8_t*)dout);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(rgb, dout, px * 3, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

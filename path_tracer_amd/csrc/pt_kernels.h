@@ -49,6 +49,7 @@ void launch_post_accumulate(hipStream_t s, uint32_t n, const f4* input, f4* accu
 void launch_post_velocity(hipStream_t s, int w, int h, const f4* position, const float* m16, float* velocity_xy);
 void launch_post_reproject(hipStream_t s, int w, int h, const f4* input, const f4* accum, const float* velocity_xy, const uint32_t* id, f4* output);
 void launch_post_tonemap(hipStream_t s, uint32_t n, const f4* accum, f4* out);
+void launch_post_rgb8(hipStream_t s, uint32_t n, const f4* accum, uint8_t* out);
 
 // unit hooks
 void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits);

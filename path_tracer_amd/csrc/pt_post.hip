@@ -5,6 +5,7 @@
 //   k_post_velocity     src/shaders/velocity.wgsl:16-39       per-pixel motion vector from the first-hit position
 //   k_post_reproject    src/shaders/compute.wgsl:103-212      3x3 YCoCg variance clip, Catmull-Rom history, id disocclusion, 15 % blend
 //   k_post_tonemap      src/shaders/shader.wgsl:3-33,59-64    Uchimura "GT" curve on accumulation.rgb / accumulation.w
+//   k_post_rgb8         src/image_helper.rs:41-48 + src/image_helper/tonemapping.rs   the 8-bit gamma-2.2 image write_image saves
 //
 // WGSL leaves bilinear filter weights, mat*vec summation order, pow/exp precision and out-of-range casts to the GPU.  Here
 // they are exact binary32 operations in the written order, pow(x, c) = exp(c ln x) with pt_math.h's routines, saturating
@@ -104,6 +105,31 @@ __device__ float gt_curve(float x, float p, float a, float m, float l, float c, 
     return maxf_w(r, 0.0f);
 }
 
+// tonemapping.rs:1-96 — the CPU-side curve differs from shader.wgsl in its branches (x < 0 -> b, branchy smoothstep, and the
+// shoulder weight gt_lerp(x, e, e) which is 0/0 = NaN at x == e exactly); restated as written.
+__device__ float gt_curve_rs(float x, float p, float a, float m, float l, float c, float b)
+{
+    if (x < 0.0f) return b;
+    const float l0 = (p - m) * l / a;
+    float sm;                                                      // gt_smoothstep(x, 0, m)  :36-52
+    if (x < 0.0f) sm = 0.0f;
+    else if (x > m) sm = 1.0f;
+    else { const float q = (x - 0.0f) / (m - 0.0f); const float r = 3.0f - 2.0f * q; sm = q * q * r; }
+    const float w0 = 1.0f - sm;
+    const float e = m + l0;
+    float w2;                                                      // gt_lerp(x, e, e)  :20-34
+    if (x < e) w2 = 0.0f;
+    else if (x > e) w2 = 1.0f;
+    else w2 = (x - e) / (e - e);
+    const float w1 = 1.0f - w0 - w2;
+    const float t = (m * pow_det(x / m, c) + b) * w0;              // gt_toe
+    const float u = (m + a * (x - m)) * w1;                        // gt_linear
+    const float s0 = m + l0, s1 = m + a * l0, c2 = a * p / (p - s1);
+    const float v = (p - (p - s1) * exp_det(-c2 * (x - s0) / p)) * w2; // gt_shoulder
+    return t + u + v;
+}
+__device__ __forceinline__ uint32_t to_u8_sat(float f) { return isnan_f(f) ? 0u : (f >= 255.0f ? 255u : (f <= 0.0f ? 0u : (uint32_t)f)); } // Rust `as u8`
+
 __global__ void __launch_bounds__(256) k_post_accumulate(uint32_t n, const f4* __restrict__ input, f4* __restrict__ accum)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,8 +214,25 @@ __global__ void __launch_bounds__(256) k_post_tonemap(uint32_t n, const f4* __re
                 gt_curve(a.z / a.w, 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f), 1.0f};
 }
 
+// one thread per pixel writes 3 bytes; a wave's 192 bytes are contiguous
+__global__ void __launch_bounds__(256) k_post_rgb8(uint32_t n, const f4* __restrict__ accum, uint8_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f4 a = accum[i];
+    const float g = 1.0f / 2.2f;
+    const float ch[3] = {a.x / a.w, a.y / a.w, a.z / a.w};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        out[(size_t)i * 3u + k] = (uint8_t)to_u8_sat(pow_det(gt_curve_rs(ch[k], 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f), g) * 255.0f);
+}
+
 } // namespace
 
+void launch_post_rgb8(hipStream_t s, uint32_t n, const f4* accum, uint8_t* out)
+{
+    hipLaunchKernelGGL(k_post_rgb8, dim3((n + 255u) / 256u), dim3(256), 0, s, n, accum, out);
+}
 void launch_post_accumulate(hipStream_t s, uint32_t n, const f4* input, f4* accum)
 {
     hipLaunchKernelGGL(k_post_accumulate, dim3((n + 255u) / 256u), dim3(256), 0, s, n, input, accum);

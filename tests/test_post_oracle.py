@@ -109,3 +109,28 @@ def test_inv_projection_inverts_the_ray_matrix(oracle_mod, cornell64):
         clip = M @ np.append(p, 1.0)
         ndc = clip[:2] / clip[3]
         assert np.abs(ndc * 0.5 + 0.5 - [s, t]).max() < 1e-4
+
+
+def test_rgb8_conversion_against_float64(oracle_mod):
+    """image_helper.rs:41-48: GT curve (tonemapping.rs, the CPU variant) -> ^(1/2.2) -> x255 -> `as u8` (truncating, saturating)"""
+    x = np.concatenate([[0.0, 1e-6, 0.22, 0.532, 0.5320001, 1.0, 50.0, -1.0], np.linspace(0, 3, 500)])
+    acc = np.zeros((1, x.size, 4), np.float32)
+    acc[0, :, 0] = (x * 3).astype(np.float32); acc[0, :, 1] = np.float32(0.3); acc[0, :, 2] = np.nan; acc[0, :, 3] = 3
+    out = oracle_mod.post_rgb8(acc)
+    xf = (acc[0, :, 0] / np.float32(3)).astype(np.float64)
+    P, a, m, l, c, b = 1.0, 1.0, 0.22, 0.4, 1.33, 0.0
+    l0 = (P - m) * l / a
+    t = np.clip(xf / m, 0, 1); w0 = 1 - t * t * (3 - 2 * t); w2 = (xf > m + l0).astype(np.float64); w1 = 1 - w0 - w2
+    s0, s1 = m + l0, m + a * l0; c2 = a * P / (P - s1)
+    with np.errstate(invalid="ignore"):
+        curve = (m * np.abs(xf / m) ** c + b) * w0 + (m + a * (xf - m)) * w1 + (P - (P - s1) * np.exp(-c2 * (xf - s0) / P)) * w2
+        curve = np.where(xf < 0, b, curve)
+        ref = np.clip(curve, 0, None) ** (1 / 2.2) * 255
+    got = out[0, :, 0].astype(np.float64)
+    near_edge = np.abs(ref - np.round(ref)) < 1e-3                                           # truncation boundary: either side is fine
+    quirk = acc[0, :, 0] / np.float32(3) == np.float32(0.22) + np.float32(0.78) * np.float32(0.4)   # x == m + l0: gt_lerp(x, e, e) = 0/0
+    assert quirk[3] and quirk.sum() == 1 and out[0, 3, 0] == 0                               # NaN weight -> NaN -> `as u8` 0, as the reference
+    assert np.all((got == np.floor(np.clip(ref, 0, 255))) | near_edge | quirk)
+    assert out[0, 0, 0] == 0 and out[0, 7, 0] == 0 and out[0, 6, 0] >= 254                    # black, negative -> b = 0, far above white
+    assert np.all(out[0, :, 2] == 0)                                                         # NaN `as u8` is 0
+    assert len(set(out[0, :, 1].tolist())) == 1

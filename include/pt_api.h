@@ -100,6 +100,14 @@ int pt_build(pt_ctx* ctx);
 
 /* ---- Camera::new / create_ray  src/camera.rs:17-31, 94-105 ---------------------------------------------------- */
 int pt_set_camera(pt_ctx* ctx, const float eye[3], const float target[3], float fov_y_deg, float aspect);
+/* Camera::input (src/camera.rs:56-92) without winit: the caller translates its window events.  PT_EV_MOUSE_MOTION carries
+ * DeviceEvent::MouseMotion's delta (a = delta.0, b = delta.1) -> update_rotation (camera.rs:41-54); PT_EV_KEY_W/S/A/D are the
+ * pressed-key arms -> update_origin (camera.rs:33-39); a, b are ignored for keys.  dt = seconds since the previous event
+ * (main.rs:144).  Returns 1 where the reference returns true (event consumed, camera changed), 0 for any other event code,
+ * negative pt_status on error.  The next pt_render / pt_frame uses the moved camera. */
+enum pt_event { PT_EV_MOUSE_MOTION = 0, PT_EV_KEY_W = 1, PT_EV_KEY_S = 2, PT_EV_KEY_A = 3, PT_EV_KEY_D = 4 };
+int pt_camera_input(pt_ctx* ctx, int event, float a, float b, float dt);
+int pt_camera_angles(pt_ctx* ctx, float pitch_yaw[2]); /* the private yaw / pitch fields (camera.rs:8-9), for tests */
 int pt_camera_matrices(pt_ctx* ctx, float cam_to_world_3x4[12], float inv_proj_4x4_colmajor[16]);
 /* ImageHelper (src/image_helper.rs:13-17) as used on a miss, integrator.rs:256-262: equirect environment, LINEAR rgb,
  * width*height*3 floats, row-major (the gamma-2.2 decode of load_image :25-33 is the caller's).  NULL / 0 restores the

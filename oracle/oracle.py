@@ -55,6 +55,9 @@ def lib():
         L.pto_set_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.pto_camera_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_inv_projection.argtypes = [C.c_void_p, C.c_void_p]
+        L.pto_camera_move.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.pto_camera_rotate.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.pto_camera_angles.argtypes = [C.c_void_p, C.c_void_p]
         L.pto_post_accumulate.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_post_velocity.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_post_reproject.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
@@ -184,6 +187,20 @@ class Oracle:
         d = np.zeros(3, np.float32)
         self.L.pto_primary_ray(self.ctx, C.byref(cfg), pixel, sample, _p(o), _p(d))
         return o, d
+
+    def camera_input(self, event, a=0.0, b=0.0, dt=0.0):
+        """Camera::input's dispatch (camera.rs:56-92); event codes as include/pt_api.h's pt_event"""
+        if event == 0:
+            self.L.pto_camera_rotate(self.ctx, a, b, dt); return True
+        moves = {1: (0.0, 1.0), 2: (0.0, -1.0), 3: (-1.0, 0.0), 4: (1.0, 0.0)}
+        if event in moves:
+            self.L.pto_camera_move(self.ctx, moves[event][0], moves[event][1], dt); return True
+        return False
+
+    def camera_angles(self):
+        out = np.zeros(2, np.float32)
+        self.L.pto_camera_angles(self.ctx, _p(out))
+        return out
 
     def inv_projection(self):
         m = np.zeros(16, np.float32)

@@ -947,6 +947,7 @@ struct Camera
     Affine matrix;    // camera-to-world
     M4 inv_projection;
     M4 ray_matrix;    // matrix * inv_projection (camera.rs:98), constant per frame
+    float yaw = 0, pitch = 0; // camera.rs:8-9 (named as the reference names them: pitch turns about Y, yaw about X)
     bool set = false;
     void init(V3 origin, V3 target, float fov_deg, float aspect)                  // camera.rs:17-31
     {
@@ -965,7 +966,68 @@ struct Camera
         M4 m4{{V4{matrix.m.c0.x, matrix.m.c0.y, matrix.m.c0.z, 0}, V4{matrix.m.c1.x, matrix.m.c1.y, matrix.m.c1.z, 0},
                V4{matrix.m.c2.x, matrix.m.c2.y, matrix.m.c2.z, 0}, V4{matrix.t.x, matrix.t.y, matrix.t.z, 1.0f}}};
         ray_matrix = mat4_mul(m4, inv_projection);
+        // camera.rs:23  let (pitch, yaw, _) = matrix.to_scale_rotation_translation().1.to_euler(glam::EulerRot::YXZ);
+        // glam 0.23 Affine3A::to_scale_rotation_translation: scale = (|x|*signum(det), |y|, |z|); rotation = Quat::from_mat3(axes * scale.recip())
+        float det = dot(matrix.m.c2, cross(matrix.m.c0, matrix.m.c1));
+        V3 scale{length(matrix.m.c0) * rs_signum(det), length(matrix.m.c1), length(matrix.m.c2)};
+        V3 inv_scale{1.0f / scale.x, 1.0f / scale.y, 1.0f / scale.z};
+        V4 q = quat_from_mat3(matrix.m.c0 * inv_scale.x, matrix.m.c1 * inv_scale.y, matrix.m.c2 * inv_scale.z);
+        // glam euler.rs, EulerRot::YXZ on a quaternion: first, second (third is dropped)
+        pitch = det_atan2(2.0f * (q.x * q.z + q.w * q.y), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z);
+        yaw = det_asin(rs_clamp(-2.0f * (q.y * q.z - q.w * q.x), -1.0f, 1.0f));
         set = true;
+    }
+    void update_ray_matrix()
+    {
+        M4 m4{{V4{matrix.m.c0.x, matrix.m.c0.y, matrix.m.c0.z, 0}, V4{matrix.m.c1.x, matrix.m.c1.y, matrix.m.c1.z, 0},
+               V4{matrix.m.c2.x, matrix.m.c2.y, matrix.m.c2.z, 0}, V4{matrix.t.x, matrix.t.y, matrix.t.z, 1.0f}}};
+        ray_matrix = mat4_mul(m4, inv_projection);
+    }
+    static V4 quat_from_mat3(V3 x_axis, V3 y_axis, V3 z_axis)                      // glam Quat::from_rotation_axes
+    {
+        float m00 = x_axis.x, m01 = x_axis.y, m02 = x_axis.z, m10 = y_axis.x, m11 = y_axis.y, m12 = y_axis.z, m20 = z_axis.x, m21 = z_axis.y, m22 = z_axis.z;
+        if (m22 <= 0.0f)
+        {
+            float dif10 = m11 - m00, omm22 = 1.0f - m22;
+            if (dif10 <= 0.0f) { float f = omm22 - dif10, i = 0.5f / std::sqrt(f); return V4{f * i, (m01 + m10) * i, (m02 + m20) * i, (m12 - m21) * i}; }
+            float f = omm22 + dif10, i = 0.5f / std::sqrt(f);
+            return V4{(m01 + m10) * i, f * i, (m12 + m21) * i, (m20 - m02) * i};
+        }
+        float sum10 = m11 + m00, opm22 = 1.0f + m22;
+        if (sum10 <= 0.0f) { float f = opm22 - sum10, i = 0.5f / std::sqrt(f); return V4{(m02 + m20) * i, (m12 + m21) * i, f * i, (m01 - m10) * i}; }
+        float f = opm22 + sum10, i = 0.5f / std::sqrt(f);
+        return V4{(m12 - m21) * i, (m20 - m02) * i, (m01 - m10) * i, f * i};
+    }
+    static V4 quat_mul(V4 lhs, V4 rhs)                                             // glam sse2 Quat::mul_quat (rtm::quat_mul)
+    {
+        auto lanes = [](V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; };
+        V4 r_wzyx{rhs.w, rhs.z, rhs.y, rhs.x}, r_zwxy{rhs.z, rhs.w, rhs.x, rhs.y}, r_yxwz{rhs.y, rhs.x, rhs.w, rhs.z};
+        V4 t0 = mul4(rhs, lhs.w);
+        V4 t1 = lanes(mul4(r_wzyx, lhs.x), V4{1.0f, -1.0f, 1.0f, -1.0f});
+        V4 t2 = lanes(mul4(r_zwxy, lhs.y), V4{1.0f, 1.0f, -1.0f, -1.0f});
+        V4 t3 = lanes(mul4(r_yxwz, lhs.z), V4{-1.0f, 1.0f, 1.0f, -1.0f});
+        return add4(add4(t0, t1), add4(t2, t3));
+    }
+    void update_origin(float dx, float dz, float dt)                               // camera.rs:33-39
+    {
+        const float sensitivity = 5.0e5f;
+        matrix.t = matrix.t + transform_vector(matrix, V3{dx, 0.0f, -dz}) * dt * sensitivity;
+        update_ray_matrix();
+    }
+    void update_rotation(float dx, float dy, float dt)                             // camera.rs:41-54
+    {
+        const float sensitivity = 1.0e4f;
+        yaw -= dy * dt * sensitivity;
+        pitch -= dx * dt * sensitivity;
+        // Quat::from_euler(YXZ, a, b, c) = rot_y(a) * rot_x(b) * rot_z(c); rot_*(t) has sin(t/2) on its axis, cos(t/2) in w
+        float sa, ca, sb, cb, sc, cc;
+        det_sincos(pitch * 0.5f, &sa, &ca); det_sincos(yaw * 0.5f, &sb, &cb); det_sincos(0.0f * 0.5f, &sc, &cc);
+        V4 q = quat_mul(quat_mul(V4{0, sa, 0, ca}, V4{sb, 0, 0, cb}), V4{0, 0, sc, cc});
+        // Affine3A::from_rotation_translation -> Mat3A::from_quat
+        float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+        matrix.m = M3{V3{1.0f - (yy + zz), xy + wz, xz - wy}, V3{xy - wz, 1.0f - (xx + zz), yz + wx}, V3{xz + wy, yz - wx, 1.0f - (xx + yy)}};
+        update_ray_matrix();
     }
     Ray create_ray(float s, float t) const                                        // camera.rs:94-105
     {
@@ -1418,6 +1480,10 @@ int pto_set_camera(pto_ctx* c, const float eye[3], const float target[3], float 
     c->camera.init(V3{eye[0], eye[1], eye[2]}, V3{target[0], target[1], target[2]}, fov_y_deg, aspect);
     return 0;
 }
+
+int pto_camera_move(pto_ctx* c, float dx, float dz, float dt) { if (!c->camera.set) return -1; c->camera.update_origin(dx, dz, dt); return 0; }
+int pto_camera_rotate(pto_ctx* c, float dx, float dy, float dt) { if (!c->camera.set) return -1; c->camera.update_rotation(dx, dy, dt); return 0; }
+int pto_camera_angles(pto_ctx* c, float out[2]) { out[0] = c->camera.pitch; out[1] = c->camera.yaw; return 0; }
 
 int pto_set_environment(pto_ctx* c, uint32_t w, uint32_t h, const float* rgb)
 {

@@ -56,6 +56,9 @@ int pto_set_environment(pto_ctx*, uint32_t w, uint32_t h, const float* rgb);
 int pto_camera_matrices(pto_ctx*, float cam_to_world_3x4[12], float inv_proj_4x4[16], float ray_matrix_4x4[16]);
 int pto_create_ray(pto_ctx*, float s, float t, float o[3], float d[3]);
 int pto_inv_projection(pto_ctx*, float out16_colmajor[16]);
+int pto_camera_move(pto_ctx*, float dx, float dz, float dt);      /* Camera::update_origin   camera.rs:33-39 */
+int pto_camera_rotate(pto_ctx*, float dx, float dy, float dt);    /* Camera::update_rotation camera.rs:41-54 */
+int pto_camera_angles(pto_ctx*, float pitch_yaw[2]);
 int pto_primary_ray(pto_ctx*, const pto_render_cfg*, uint32_t pixel, uint32_t sample, float o[3], float d[3]);
 
 int pto_render(pto_ctx*, const pto_render_cfg*, float* accum_rgba, float* position_xyzt, uint32_t* id, uint64_t* counters);

@@ -29,10 +29,13 @@ DEFAULT_SEED = 0x5EED5EED
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
-    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
+    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
 ]
+
+
+EV_MOUSE_MOTION, EV_KEY_W, EV_KEY_S, EV_KEY_A, EV_KEY_D = range(5)
 
 
 class MaterialDesc(C.Structure):
@@ -106,6 +109,8 @@ def lib():
         L.pt_set_stream.argtypes = [vp, vp]
         L.pt_synchronize.argtypes = [vp]
         L.pt_frame.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.pt_camera_input.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.pt_camera_angles.argtypes = [vp, vp]
         L.pt_inv_projection.argtypes = [vp, vp]
         L.pt_present.argtypes = [vp, vp]
         L.pt_post_velocity.argtypes = [vp, u32, u32, vp, vp, vp]
@@ -197,6 +202,15 @@ class Renderer:
 
     def set_camera(self, cam: CameraDesc):
         self._chk(self.L.pt_set_camera(self.ctx, _f3(cam.origin), _f3(cam.target), cam.fov, cam.aspect_ratio))
+
+    def camera_input(self, event, a=0.0, b=0.0, dt=0.0) -> bool:
+        """Camera::input (camera.rs:56-92): event = EV_MOUSE_MOTION (a, b = delta) or EV_KEY_W/S/A/D; True if consumed"""
+        return bool(self._chk(self.L.pt_camera_input(self.ctx, int(event), a, b, dt), allow_positive=True))
+
+    def camera_angles(self):
+        out = np.zeros(2, np.float32)
+        self._chk(self.L.pt_camera_angles(self.ctx, _p(out)))
+        return out
 
     def set_environment(self, rgb):
         """rgb: (h, w, 3) linear float32 equirect image, or None for the constant-ambient branch."""

@@ -655,6 +655,32 @@ int pt_set_camera(pt_ctx* c, const float eye[3], const float target[3], float fo
     return PT_OK;
 }
 
+int pt_camera_input(pt_ctx* c, int event, float a, float b, float dt)                   // Camera::input  camera.rs:56-92
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->scene.camera.set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
+    switch (event)
+    {
+    case PT_EV_MOUSE_MOTION: c->scene.camera_rotate(a, b, dt); return 1;
+    case PT_EV_KEY_W: c->scene.camera_move(0.0f, 1.0f, dt); return 1;
+    case PT_EV_KEY_S: c->scene.camera_move(0.0f, -1.0f, dt); return 1;
+    case PT_EV_KEY_A: c->scene.camera_move(-1.0f, 0.0f, dt); return 1;
+    case PT_EV_KEY_D: c->scene.camera_move(1.0f, 0.0f, dt); return 1;
+    default: return 0;
+    }
+}
+
+int pt_camera_angles(pt_ctx* c, float pitch_yaw[2])
+{
+    if (!c || !pitch_yaw) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->scene.camera.set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
+    pitch_yaw[0] = c->scene.camera.pitch;
+    pitch_yaw[1] = c->scene.camera.yaw;
+    return PT_OK;
+}
+
 int pt_set_environment(pt_ctx* c, uint32_t width, uint32_t height, const float* rgb_linear)
 {
     if (!c) return PT_ERR_ARG;

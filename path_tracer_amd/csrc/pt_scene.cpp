@@ -595,6 +595,60 @@ int HostScene::flatten(std::string* err)
     return 0;
 }
 
+namespace {
+// ---- the few glam 0.23 quaternion routines Camera needs (camera.rs:23, 46-49), in glam's operation order
+struct quat { float x, y, z, w; };
+
+quat quat_mul(quat l, quat r)                                                            // Quat::mul_quat, SSE2 (rtm::quat_mul) lane formulas
+{
+    return quat{(l.w * r.x + l.x * r.w) + (l.y * r.z + -(l.z * r.y)),
+                (l.w * r.y + -(l.x * r.z)) + (l.y * r.w + l.z * r.x),
+                (l.w * r.z + l.x * r.y) + (-(l.y * r.x) + l.z * r.w),
+                (l.w * r.w + -(l.x * r.x)) + (-(l.y * r.y) + -(l.z * r.z))};
+}
+
+quat quat_from_axes(f3 ax, f3 ay, f3 az)                                                 // Quat::from_rotation_axes (from_mat3)
+{
+    const float m00 = ax.x, m01 = ax.y, m02 = ax.z, m10 = ay.x, m11 = ay.y, m12 = ay.z, m20 = az.x, m21 = az.y, m22 = az.z;
+    if (m22 <= 0.0f)
+    {
+        const float dif10 = m11 - m00, omm22 = 1.0f - m22;
+        if (dif10 <= 0.0f)
+        {
+            const float four_xsq = omm22 - dif10, inv4x = 0.5f / std::sqrt(four_xsq);
+            return quat{four_xsq * inv4x, (m01 + m10) * inv4x, (m02 + m20) * inv4x, (m12 - m21) * inv4x};
+        }
+        const float four_ysq = omm22 + dif10, inv4y = 0.5f / std::sqrt(four_ysq);
+        return quat{(m01 + m10) * inv4y, four_ysq * inv4y, (m12 + m21) * inv4y, (m20 - m02) * inv4y};
+    }
+    const float sum10 = m11 + m00, opm22 = 1.0f + m22;
+    if (sum10 <= 0.0f)
+    {
+        const float four_zsq = opm22 - sum10, inv4z = 0.5f / std::sqrt(four_zsq);
+        return quat{(m02 + m20) * inv4z, (m12 + m21) * inv4z, four_zsq * inv4z, (m01 - m10) * inv4z};
+    }
+    const float four_wsq = opm22 + sum10, inv4w = 0.5f / std::sqrt(four_wsq);
+    return quat{(m12 - m21) * inv4w, (m20 - m02) * inv4w, (m01 - m10) * inv4w, four_wsq * inv4w};
+}
+
+void euler_yxz_of(quat q, float* first, float* second)                                   // EulerRot::YXZ convert_quat (first, second)
+{
+    *first = atan2_det(2.0f * (q.x * q.z + q.w * q.y), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z);
+    float v = -2.0f * (q.y * q.z - q.w * q.x);
+    v = v < -1.0f ? -1.0f : v;                                                           // arc_clamp
+    v = v > 1.0f ? 1.0f : v;
+    *second = asin_det(v);
+}
+
+m33 mat3_of_quat(quat q)                                                                 // Mat3A::from_quat
+{
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    return m33{f3{1.0f - (yy + zz), xy + wz, xz - wy}, f3{xy - wz, 1.0f - (xx + zz), yz + wx}, f3{xz + wy, yz - wx, 1.0f - (xx + yy)}};
+}
+
+} // namespace
+
 void HostScene::set_camera(const float eye_[3], const float target_[3], float fov_deg, float aspect)     // Camera::new  camera.rs:17-31
 {
     const f3 eye{eye_[0], eye_[1], eye_[2]}, target{target_[0], target_[1], target_[2]};
@@ -611,10 +665,47 @@ void HostScene::set_camera(const float eye_[3], const float target_[3], float fo
     const float fl = 1.0f / tan_det(0.5f * fov);
     const float proj[16] = {fl / aspect, 0, 0, 0, 0, fl, 0, 0, 0, 0, -1.0f, -1.0f, 0, 0, -1.0f, 0};
     mat4_inverse(proj, camera.inv_proj);
+    refresh_ray_matrix();
+    // (pitch, yaw, _) = matrix.to_scale_rotation_translation().1.to_euler(EulerRot::YXZ)   camera.rs:23
+    const m33& r = camera.matrix.m;
+    const float det = dot3(r.c2, cross3(r.c0, r.c1));                                   // Mat3A::determinant
+    const float sgn = det != det ? det : (std::signbit(det) ? -1.0f : 1.0f);            // f32::signum
+    const float sx = 1.0f / (std::sqrt(dot3(r.c0, r.c0)) * sgn), sy = 1.0f / std::sqrt(dot3(r.c1, r.c1)), sz = 1.0f / std::sqrt(dot3(r.c2, r.c2));
+    const quat q = quat_from_axes(r.c0 * sx, r.c1 * sy, r.c2 * sz);
+    euler_yxz_of(q, &camera.pitch, &camera.yaw);
+    camera.set = true;
+}
+
+void HostScene::refresh_ray_matrix()
+{
     const xf34& m = camera.matrix;
     const float m4[16] = {m.m.c0.x, m.m.c0.y, m.m.c0.z, 0, m.m.c1.x, m.m.c1.y, m.m.c1.z, 0, m.m.c2.x, m.m.c2.y, m.m.c2.z, 0, m.t.x, m.t.y, m.t.z, 1.0f};
     mat4_mul(m4, camera.inv_proj, camera.ray_matrix);
-    camera.set = true;
+}
+
+void HostScene::camera_move(float dx, float dz, float dt)                                // Camera::update_origin  camera.rs:33-39
+{
+    const float sensitivity = 5.0e5f;
+    const f3 step = mul(camera.matrix.m, f3{dx, 0.0f, -dz});                             // transform_vector3a
+    camera.matrix.t = camera.matrix.t + (step * dt) * sensitivity;
+    refresh_ray_matrix();
+}
+
+void HostScene::camera_rotate(float dx, float dy, float dt)                              // Camera::update_rotation  camera.rs:41-54
+{
+    const float sensitivity = 1.0e4f;
+    camera.yaw -= (dy * dt) * sensitivity;
+    camera.pitch -= (dx * dt) * sensitivity;
+    // Quat::from_euler(EulerRot::YXZ, pitch, yaw, 0.0) = (rot_y(pitch) * rot_x(yaw)) * rot_z(0)
+    float s, c;
+    sincos_det(camera.pitch * 0.5f, &s, &c);
+    const quat qy{0.0f, s, 0.0f, c};
+    sincos_det(camera.yaw * 0.5f, &s, &c);
+    const quat qx{s, 0.0f, 0.0f, c};
+    sincos_det(0.0f * 0.5f, &s, &c);
+    const quat qz{0.0f, 0.0f, s, c};
+    camera.matrix.m = mat3_of_quat(quat_mul(quat_mul(qy, qx), qz));                      // Affine3A::from_rotation_translation
+    refresh_ray_matrix();
 }
 
 void HostScene::inv_projection(float out16[16]) const { mat4_inverse(camera.ray_matrix, out16); }

@@ -62,6 +62,7 @@ struct HostLight { uint32_t blas, prim; float pdf, cdf; };
 struct HostCamera
 {
     bool set = false;
+    float yaw = 0, pitch = 0; // as the reference names them: pitch is the Y angle, yaw the X angle of EulerRot::YXZ (camera.rs:23)
     xf34 matrix;          // camera-to-world
     float inv_proj[16];   // column-major
     float ray_matrix[16]; // matrix * inv_projection, column-major
@@ -107,12 +108,15 @@ public:
     void set_camera(const float eye[3], const float target[3], float fov_deg, float aspect);
     void create_ray(float s, float t, float o[3], float d[3]) const;
     void inv_projection(float out16[16]) const; // (matrix * inv_projection).inverse()  main.rs:128
+    void camera_move(float dx, float dz, float dt);   // Camera::update_origin    camera.rs:33-39
+    void camera_rotate(float dx, float dy, float dt); // Camera::update_rotation  camera.rs:41-54
 
 private:
     void build_blas(HostBlas& out, const HostModel& m);
     void build_tlas(HostTlas& out, const std::vector<uint32_t>& model_ids);
     void build_lights();
     int flatten(std::string* err);
+    void refresh_ray_matrix();
 };
 
 } // namespace pt

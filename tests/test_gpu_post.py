@@ -118,6 +118,37 @@ def test_frame_sequence_static_then_moving_camera(api, oracle_mod, cornell64):
     assert np.isfinite(r.present()).all()
 
 
+def test_interactive_loop_driven_by_camera_input(api, oracle_mod, cornell64):
+    """main.rs:141-218 end to end: events move the camera (Camera::input), each MainEventsCleared traces one sample and updates
+    the accumulation; compared with the oracle after every frame"""
+    W = H = 48
+    from path_tracer_amd import scenes
+    sc = scenes.cornell_box(W, H)
+    r = api.Renderer(sc, W, H, max_bounces=3); o = oracle_mod.Oracle(sc)
+    events = [None, None, (api.EV_KEY_W, 0, 0, 2e-4), (api.EV_MOUSE_MOTION, 4.0, -1.5, 1e-5), None, (api.EV_KEY_D, 0, 0, 1e-4), (api.EV_KEY_S, 0, 0, 3e-4),
+              (api.EV_MOUSE_MOTION, -9.0, 2.0, 1e-5), (api.EV_KEY_A, 0, 0, 1e-4), None]
+    acc = np.zeros((H, W, 4), np.float32)
+    id_g = np.zeros((H, W), np.uint32); id_o = np.zeros((H, W), np.uint32)
+    last = o.inv_projection()
+    moved = 0
+    for k, ev in enumerate(events):
+        if ev is not None:
+            assert r.camera_input(*ev) and o.camera_input(*ev)
+        data_g, pos_g, id_g = r.frame(k, last, id_g)
+        data_o, pos_o, id_o, _ = o.render(W, H, 1, first_sample=k, max_bounces=3, ident=id_o)
+        assert_bit_equal(data_g, data_o, f"frame {k} data"); assert_bit_equal(pos_g, pos_o, f"frame {k} position"); assert_bit_equal(id_g, id_o, f"frame {k} id")
+        cur = o.inv_projection()
+        if np.array_equal(cur, last):
+            acc = oracle_mod.post_accumulate(data_o, acc)
+        else:
+            acc = oracle_mod.post_reproject(data_o, acc, oracle_mod.post_velocity(pos_o, last), id_o); moved += 1
+        assert_same(r.read_accumulation(), acc, f"frame {k} accumulation")
+        last = cur
+        assert_bit_equal(r.inv_projection(), cur, "inv_projection")
+    assert moved == 6
+    assert np.array_equal(r.present_rgb8(), oracle_mod.post_rgb8(acc))
+
+
 def _read_png(path):
     import struct
     import zlib

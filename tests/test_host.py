@@ -179,3 +179,85 @@ def test_obj_loader_errors(api, tmp_path, text, code):
     with pytest.raises(api.PtError) as e:
         api.Renderer(sc, 8, 8)
     assert e.value.code == -6
+
+
+# ---------------------------------------------------------------- Camera::input (camera.rs:33-92), host only
+def _cam_state(x):
+    m, ip = x.camera_matrices()[:2]
+    return np.concatenate([m.ravel(), ip.ravel(), x.inv_projection().ravel(), x.camera_angles().ravel()])
+
+
+def test_camera_new_derives_the_euler_angles(api, oracle_mod, cornell64):
+    """camera.rs:23: the reference camera looks down -z, so both angles are zero; an arbitrary camera round-trips through
+    update_rotation(0, 0) (angles -> quaternion -> matrix) to the same orientation"""
+    from path_tracer_amd.scene_desc import Camera
+    r = api.Renderer(cornell64, 64, 64); o = oracle_mod.Oracle(cornell64)
+    assert np.all(np.abs(r.camera_angles()) == 0)
+    cam = Camera.new((300.0, 220.0, 700.0), (-40.0, 10.0, -90.0), 50.0, 1.5)
+    r.set_camera(cam); o.set_camera(cam)
+    assert_bit_equal(_cam_state(r), _cam_state(o), "state after Camera::new")
+    before, _ = r.camera_matrices()
+    assert r.camera_input(api.EV_MOUSE_MOTION, 0.0, 0.0, 0.016)
+    after, _ = r.camera_matrices()
+    assert np.abs(before - after).max() < 2e-4 * max(1.0, np.abs(before).max())
+    rot = after.reshape(3, 4)[:, :3].astype(np.float64)
+    assert np.abs(rot @ rot.T - np.eye(3)).max() < 1e-6
+
+
+def test_camera_input_matches_oracle_over_an_event_sequence(api, oracle_mod, cornell64):
+    r = api.Renderer(cornell64, 64, 64); o = oracle_mod.Oracle(cornell64)
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        ev = int(rng.integers(0, 5))
+        a, b = (float(np.float32(rng.normal() * 6)), float(np.float32(rng.normal() * 6))) if ev == 0 else (0.0, 0.0)
+        dt = float(np.float32(rng.uniform(1e-5, 4e-4)))
+        assert r.camera_input(ev, a, b, dt) is True and o.camera_input(ev, a, b, dt) is True
+        assert_bit_equal(_cam_state(r), _cam_state(o), f"state after event {k} ({ev})")
+        for s, t in ((0.5, 0.5), (0.03, 0.91)):
+            go, gd = r.create_ray(s, t); co, cd = o.create_ray(s, t)
+            assert_bit_equal(go, co, "ray origin"); assert_bit_equal(gd, cd, "ray direction")
+    assert r.camera_input(17) is False and o.camera_input(17) is False                          # any other event: not consumed
+
+
+def test_camera_keys_move_along_the_view_axes(api, cornell64):
+    """update_origin: translation += matrix * (dx, 0, -dz) * dt * 5e5 — W/S along the view direction, A/D along the camera's x"""
+    r = api.Renderer(cornell64, 64, 64)
+    eye0, fwd = r.create_ray(0.5, 0.5)
+    dt = 1e-4
+    r.camera_input(api.EV_KEY_W, dt=dt)
+    eye1, fwd1 = r.create_ray(0.5, 0.5)
+    assert np.allclose(eye1 - eye0, fwd * np.float32(dt) * np.float32(5e5), atol=1e-3) and np.allclose(fwd1, fwd, atol=1e-6)
+    r.camera_input(api.EV_KEY_S, dt=dt)
+    assert np.allclose(r.create_ray(0.5, 0.5)[0], eye0, atol=1e-3)
+    r.camera_input(api.EV_KEY_D, dt=dt)
+    eye2, _ = r.create_ray(0.5, 0.5)
+    right = (eye2 - eye0) / np.linalg.norm(eye2 - eye0)
+    assert abs(float(right @ fwd)) < 1e-5 and right[0] > 0.99                                   # +x for the reference camera
+    r.camera_input(api.EV_KEY_A, dt=dt)
+    assert np.allclose(r.create_ray(0.5, 0.5)[0], eye0, atol=1e-3)
+
+
+def test_camera_mouse_turns_about_y_then_x(api, cornell64):
+    """update_rotation: `pitch` (the Y angle of EulerRot::YXZ) -= delta.0 * dt * 1e4, `yaw` (the X angle) -= delta.1 * dt * 1e4"""
+    r = api.Renderer(cornell64, 64, 64)
+    dt = 1e-5
+    r.camera_input(api.EV_MOUSE_MOTION, 3.0, 0.0, dt)                                           # 0.3 rad about Y, towards +x (right)
+    assert np.allclose(r.camera_angles(), [-0.3, 0.0], atol=1e-6)
+    _, d = r.create_ray(0.5, 0.5)
+    assert np.allclose(d, [np.sin(0.3), 0.0, -np.cos(0.3)], atol=1e-5)
+    r.camera_input(api.EV_MOUSE_MOTION, 0.0, 2.0, dt)                                           # then 0.2 rad about the camera's x: down
+    assert np.allclose(r.camera_angles(), [-0.3, -0.2], atol=1e-6)
+    _, d = r.create_ray(0.5, 0.5)
+    assert np.allclose(d, [np.sin(0.3) * np.cos(0.2), -np.sin(0.2), -np.cos(0.3) * np.cos(0.2)], atol=1e-5)
+    eye, _ = r.create_ray(0.5, 0.5)
+    assert np.allclose(eye, [0.0, 50.0, 1000.0])                                                # rotation keeps the translation
+
+
+def test_camera_input_before_set_camera_is_a_state_error(api):
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import SceneDesc
+    sc = scenes.cornell_box(64, 64)
+    r = api.Renderer(SceneDesc.new(sc.models, None), 64, 64)
+    with pytest.raises(api.PtError) as e:
+        r.camera_input(api.EV_KEY_W, dt=0.01)
+    assert e.value.code == -3

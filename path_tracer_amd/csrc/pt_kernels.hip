@@ -156,22 +156,27 @@ __device__ __forceinline__ f3 xyz(const f4& v) { return f3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 
-// AABB::intersect / intersect_t (boundingbox.rs:97-131).  The reference's glam min/max are SSE selects
-// (second operand wins on NaN).  With t_max not NaN every second operand below is NaN-free, so IEEE minNum/maxNum
-// (v_min_f32/v_max_f32) return the same values; zero-sign differences cannot reach the result because t_smaller >= EPS.
-// Callers guarantee t_max is not NaN (NaN t_max makes every reference box test fail; handled at the call sites).
+// AABB::intersect / intersect_t (boundingbox.rs:97-131):
+//   t0 = (min - o) * inv, t1 = (max - o) * inv;  t_small = min(max(t0, EPS), max(t1, EPS));  t_big = max(min(t0, t_max), min(t1, t_max));
+//   hit iff max_element(t_small) <= min_element(t_big), t_enter = max_element(t_small)      (glam min/max = SSE selects: b wins on NaN)
+// evaluated with half the min/max work by picking, per axis, the plane the ray reaches first.  Subtraction and the multiply by
+// inv are monotone, so for inv >= 0 (incl. +inf) t0 <= t1 and for inv < 0 (incl. -inf) t1 <= t0 whenever both are numbers; then
+// t_small = max(t_near, EPS) and t_big = min(t_far, t_max) exactly.  A NaN arises only as 0 * inf (origin on the plane, zero
+// direction component): the reference's selects turn that axis into (EPS, t_max), i.e. no constraint, and so do IEEE
+// maxNum/minNum (v_max3_f32/v_min3_f32), which drop a NaN operand.  If both planes give NaN the axis is unconstrained on both
+// sides as well.  Zero signs cannot reach the result (t_enter >= EPS; t_big is only compared).  Requires t_max not NaN (a NaN
+// t_max fails every reference box test; call sites handle it).
 __device__ __forceinline__ bool slab(const uint4 w0, const uint4 w1, const f3 o, const f3 inv, const float t_max, float& t_enter)
 {
-    const float t0x = (asf(w0.x) - o.x) * inv.x, t0y = (asf(w0.y) - o.y) * inv.y, t0z = (asf(w0.z) - o.z) * inv.z;
-    const float t1x = (asf(w1.x) - o.x) * inv.x, t1y = (asf(w1.y) - o.y) * inv.y, t1z = (asf(w1.z) - o.z) * inv.z;
-    const float sx = fminf(fmaxf(t0x, PT_EPSILON), fmaxf(t1x, PT_EPSILON));
-    const float sy = fminf(fmaxf(t0y, PT_EPSILON), fmaxf(t1y, PT_EPSILON));
-    const float sz = fminf(fmaxf(t0z, PT_EPSILON), fmaxf(t1z, PT_EPSILON));
-    const float bx = fmaxf(fminf(t0x, t_max), fminf(t1x, t_max));
-    const float by = fmaxf(fminf(t0y, t_max), fminf(t1y, t_max));
-    const float bz = fmaxf(fminf(t0z, t_max), fminf(t1z, t_max));
-    const float ts = fmaxf(fmaxf(sx, sz), fmaxf(sy, sz));
-    const float tb = fminf(fminf(bx, bz), fminf(by, bz));
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    // (near, far) pairs: one v_pk_add_f32 + one v_pk_mul_f32 per axis
+    typedef float pair_t __attribute__((ext_vector_type(2)));
+    const pair_t px = (pair_t{asf(nx ? w1.x : w0.x), asf(nx ? w0.x : w1.x)} - pair_t{o.x, o.x}) * pair_t{inv.x, inv.x};
+    const pair_t py = (pair_t{asf(ny ? w1.y : w0.y), asf(ny ? w0.y : w1.y)} - pair_t{o.y, o.y}) * pair_t{inv.y, inv.y};
+    const pair_t pz = (pair_t{asf(nz ? w1.z : w0.z), asf(nz ? w0.z : w1.z)} - pair_t{o.z, o.z}) * pair_t{inv.z, inv.z};
+    const float tnx = px.x, tfx = px.y, tny = py.x, tfy = py.y, tnz = pz.x, tfz = pz.y;
+    const float ts = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), PT_EPSILON);
+    const float tb = fminf(fminf(fminf(tfx, tfy), tfz), t_max);
     t_enter = ts;
     return ts <= tb;
 }
@@ -294,8 +299,59 @@ struct ClosestOut
     uint32_t finalize_miss;               // 0 when an environment map is set: misses then go to the terminal queue like any bounce
 };
 
+// Per-lane traversal stack of (node, t_enter) entries.  The position `sp` is opaque to the traversal loop:
+//  * Stack8<false> (the whole stack fits the LDS budget): sp IS the entry's byte offset inside the workgroup's dynamic LDS, so a push
+//    or pop is one ds_write_b64 / ds_read_b64 with no address arithmetic beyond the add that moves sp;
+//  * Stack8<true> (BVH deeper than PT_STACK_LDS_LEVELS): sp is the level; the deepest levels live in global memory
+//    ([level][global lane], coalesced) so that occupancy does not collapse.  LDS and global accesses stay separate instructions
+//    (no flat addressing).
+template <bool SPILL>
+struct Stack8;
+template <>
+struct Stack8<false>
+{
+    char* base;             // start of dynamic LDS
+    uint32_t bottom, step;  // this lane's level-0 offset; bytes per level (8 * blockDim.x)
+    __device__ __forceinline__ static Stack8 make(uint4* smem, uint32_t blob_words, const SceneView&)
+    {
+        return Stack8{reinterpret_cast<char*>(smem), blob_words * 16u + threadIdx.x * 8u, blockDim.x * 8u};
+    }
+    __device__ __forceinline__ uint32_t empty() const { return bottom; }
+    __device__ __forceinline__ uint32_t up(uint32_t sp) const { return sp + step; }
+    __device__ __forceinline__ uint32_t down(uint32_t sp) const { return sp - step; }
+    __device__ __forceinline__ uint2 get(uint32_t sp) const { return *reinterpret_cast<const uint2*>(base + sp); }
+    __device__ __forceinline__ void put(uint32_t sp, uint2 v) const { *reinterpret_cast<uint2*>(base + sp) = v; }
+};
+template <>
+struct Stack8<true>
+{
+    uint2* lds;
+    uint2* spill;
+    uint32_t stride, lds_levels, spill_stride;
+    __device__ __forceinline__ static Stack8 make(uint4* smem, uint32_t blob_words, const SceneView& sv)
+    {
+        return Stack8{reinterpret_cast<uint2*>(smem + blob_words) + threadIdx.x,
+                      reinterpret_cast<uint2*>(sv.stack_spill) + (blockIdx.x * blockDim.x + threadIdx.x), blockDim.x, sv.stack_lds, gridDim.x * blockDim.x};
+    }
+    __device__ __forceinline__ uint32_t empty() const { return 0u; }
+    __device__ __forceinline__ uint32_t up(uint32_t sp) const { return sp + 1u; }
+    __device__ __forceinline__ uint32_t down(uint32_t sp) const { return sp - 1u; }
+    __device__ __forceinline__ uint2 get(uint32_t sp) const
+    {
+        uint2 v;
+        if (sp < lds_levels) v = lds[__umul24(sp, stride)];
+        else v = spill[(size_t)(sp - lds_levels) * spill_stride];
+        return v;
+    }
+    __device__ __forceinline__ void put(uint32_t sp, uint2 v) const
+    {
+        if (sp < lds_levels) lds[__umul24(sp, stride)] = v;
+        else spill[(size_t)(sp - lds_levels) * spill_stride] = v;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ closest hit
-template <bool LDS_SCENE, int MODE>
+template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                                   const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
                                                   const ClosestOut out)
@@ -303,21 +359,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    // per-lane stack of (node, t_enter): [level][thread] in LDS (conflict-free ds_read_b64); a BVH deeper than the LDS budget
-    // spills its deepest levels to global memory ([level][global lane], coalesced) so that occupancy does not collapse
-    struct LaneStack
-    {
-        uint2* lds;
-        uint2* spill;
-        uint32_t stride, lds_levels, spill_stride;
-        __device__ __forceinline__ uint2& at(uint32_t level) const
-        {
-            return level < lds_levels ? lds[level * stride] : spill[(size_t)(level - lds_levels) * spill_stride];
-        }
-    };
-    const uint32_t stride = blockDim.x;
-    const LaneStack stack{reinterpret_cast<uint2*>(smem + blob_words) + threadIdx.x,
-                          reinterpret_cast<uint2*>(sv.stack_spill) + (blockIdx.x * blockDim.x + threadIdx.x), stride, sv.stack_lds, gridDim.x * blockDim.x};
+    // per-lane stack of (node, t_enter), [level][thread] in LDS (conflict-free ds_read_b64 / ds_write_b64)
+    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv);
     const uint32_t n = *n_ptr;
     const uint32_t prim_bits = sv.prim_bits;
 
@@ -325,7 +368,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
-    uint32_t bid = MISS_ID, sp = 0, blas_base = 0, inst = 0;
+    uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0;
     bool in_blas = false;
     bool any_phase = false;   // CLOSEST_LIGHTS: the lights-TLAS hit exists, now any-hit against the world (integrator.rs:103)
     uint32_t chain_code = 0u; // 0 light visible, 1 blocked, 2 no light on the ray
@@ -471,14 +514,14 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 bu = 0.0f;
                 bv = 0.0f;
                 in_blas = false;
-                sp = 0;
+                sp = stk.empty();
                 // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
                 float te;
                 const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
-                    stack.at(0u) = make_uint2(root, 0u);
-                    sp = 1;
+                    stk.put(sp, make_uint2(root, 0u));
+                    sp = stk.up(sp);
                     active = true;
                 }
                 else { pending = true; }
@@ -496,19 +539,21 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             if (MODE == CLOSEST_LIGHTS && any_phase)
             {
                 // TLAS::any_intersect on the world with t_max = light_t * (1 - EPS)   tlas.rs:111-144, blas.rs:257-294
-                if (sp == 0u) { active = false; pending = true; chain_code = 0u; continue; }
-                sp -= 1u;
-                const uint32_t id = stack.at(sp).x;
+                if (sp == stk.empty()) { active = false; pending = true; chain_code = 0u; continue; }
+                sp = stk.down(sp);
+                const uint32_t id = stk.get(sp).x;
                 const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
                 float t_enter;
-                const bool hit = in_blas ? slab(n0, n1, ob.o, ob.inv, t_max, t_enter) : slab(n0, n1, w.o, w.inv, t_max, t_enter);
+                const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
+                const bool hit = slab(n0, n1, so, sinv, t_max, t_enter);
                 if (!hit) continue;
                 const uint32_t ka = n0.w, kkind = n1.w >> NODE_KIND_SHIFT, kb = n1.w & NODE_PAYLOAD_MASK;
                 if (kkind == NODE_BRANCH)
                 {
-                    stack.at(sp) = make_uint2(ka, 0u);
-                    stack.at(sp + 1u) = make_uint2(kb, 0u);
-                    sp += 2u;
+                    stk.put(sp, make_uint2(ka, 0u));
+                    sp = stk.up(sp);
+                    stk.put(sp, make_uint2(kb, 0u));
+                    sp = stk.up(sp);
                 }
                 else if (kkind == NODE_TRIS)
                 {
@@ -531,12 +576,12 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     ob = to_object(bl, ka, w, ray_finite, blas_root);
                     in_blas = true;
                     blas_base = sp;
-                    stack.at(sp) = make_uint2(blas_root, 0u);
-                    sp += 1u;
+                    stk.put(sp, make_uint2(blas_root, 0u));
+                    sp = stk.up(sp);
                 }
                 continue;
             }
-            if (sp == 0u)
+            if (sp == stk.empty())
             {
                 if (MODE == CLOSEST_LIGHTS && bid != MISS_ID)
                 {
@@ -545,7 +590,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     any_phase = true;
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
-                    if (t_max == t_max) { stack.at(0u) = make_uint2(out.world_root, 0u); sp = 1u; }
+                    if (t_max == t_max) { stk.put(sp, make_uint2(out.world_root, 0u)); sp = stk.up(sp); }
                     else { active = false; pending = true; chain_code = 0u; } // NaN t_max: every box test fails -> visible
                     continue;
                 }
@@ -553,8 +598,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 pending = true;
                 continue;
             }
-            sp -= 1u;
-            const uint2 e = stack.at(sp);
+            sp = stk.down(sp);
+            const uint2 e = stk.get(sp);
             if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
             const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
             const uint32_t a = nw[3];
@@ -570,15 +615,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);
                 const bool hr = slab(r0, r1, o, inv, t_max, tr);
-                if (hl && hr)
-                {
-                    const bool left_near = tl < tr;
-                    stack.at(sp) = left_near ? make_uint2(b, asu(tr)) : make_uint2(a, asu(tl));
-                    stack.at(sp + 1u) = left_near ? make_uint2(a, asu(tl)) : make_uint2(b, asu(tr));
-                    sp += 2u;
-                }
-                else if (hl) { stack.at(sp) = make_uint2(a, asu(tl)); sp += 1u; }
-                else if (hr) { stack.at(sp) = make_uint2(b, asu(tr)); sp += 1u; }
+                // both hit: the farther child goes underneath (ties: left underneath, right popped first); one hit: that child
+                const bool left_near = tl < tr;
+                const uint2 le = make_uint2(a, asu(tl)), re = make_uint2(b, asu(tr));
+                if (hl && hr) { stk.put(sp, left_near ? re : le); sp = stk.up(sp); }
+                if (hl || hr) { stk.put(sp, (hl && (left_near || !hr)) ? le : re); sp = stk.up(sp); }
             }
             else if (kind == NODE_TRIS)
             {
@@ -595,7 +636,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         bv = vd / det;
                         t_max = bt;
                         bid = (inst << prim_bits) | (a + k);
-                        if (bt != bt) { sp = 0u; in_blas = false; break; } // NaN t_max: nothing else can be accepted
+                        if (bt != bt) { sp = stk.empty(); in_blas = false; break; } // NaN t_max: nothing else can be accepted
                     }
                 }
             }
@@ -607,8 +648,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 inst = a;
                 in_blas = true;
                 blas_base = sp;
-                stack.at(sp) = make_uint2(blas_root, 0u); // root pushed without a box test  blas.rs:217
-                sp += 1u;
+                stk.put(sp, make_uint2(blas_root, 0u)); // root pushed without a box test  blas.rs:217
+                sp = stk.up(sp);
             }
         }
     }
@@ -646,15 +687,18 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    uint32_t* const stack = reinterpret_cast<uint32_t*>(smem + blob_words) + threadIdx.x;
-    const uint32_t stride = blockDim.x;
+    // per-lane stack of node ids, [level][thread] in LDS; sp is the byte offset of the next free slot inside dynamic LDS
+    char* const lds_bytes = reinterpret_cast<char*>(smem);
+    const uint32_t sp_empty = blob_words * 16u + threadIdx.x * 4u, sp_step = blockDim.x * 4u;
+    auto st_get = [&](uint32_t at) { return *reinterpret_cast<const uint32_t*>(lds_bytes + at); };
+    auto st_put = [&](uint32_t at, uint32_t v) { *reinterpret_cast<uint32_t*>(lds_bytes + at) = v; };
     const uint32_t n = *n_ptr;
 
     bool active = false, ray_finite = false;
     uint32_t out_idx = 0, valid_rays = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f;
-    uint32_t sp = 0, blas_base = 0;
+    uint32_t sp = sp_empty, blas_base = 0;
     bool in_blas = false;
     const uint32_t chunk = fetch_chunk_size(n);
     WaveRange wr = first_range(n, chunk);
@@ -687,8 +731,8 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 {
                     if (t_max == t_max)
                     {
-                        stack[0] = root;
-                        sp = 1;
+                        st_put(sp_empty, root);
+                        sp = sp_empty + sp_step;
                         in_blas = false;
                         active = true;
                     }
@@ -705,24 +749,25 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
         {
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false;
-            if (sp == 0u)
+            if (sp == sp_empty)
             {
                 active = false;
                 occluded[out_idx] = 0u;
                 continue;
             }
-            sp -= 1u;
-            const uint32_t id = stack[sp * stride];
+            sp -= sp_step;
+            const uint32_t id = st_get(sp);
             const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
             float t_enter;
-            const bool hit = in_blas ? slab(n0, n1, ob.o, ob.inv, t_max, t_enter) : slab(n0, n1, w.o, w.inv, t_max, t_enter);
+            const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
+            const bool hit = slab(n0, n1, so, sinv, t_max, t_enter);
             if (!hit) continue;                              // tlas.rs:118-121 / blas.rs:264
             const uint32_t a = n0.w, kind = n1.w >> NODE_KIND_SHIFT, b = n1.w & NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
             {
-                stack[sp * stride] = a;                      // left then right: right is popped first
-                stack[(sp + 1u) * stride] = b;
-                sp += 2u;
+                st_put(sp, a);                               // left then right: right is popped first
+                st_put(sp + sp_step, b);
+                sp += 2u * sp_step;
             }
             else if (kind == NODE_TRIS)
             {
@@ -744,8 +789,8 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 ob = to_object(bl, a, w, ray_finite, blas_root);
                 in_blas = true;
                 blas_base = sp;
-                stack[sp * stride] = blas_root;              // BLAS root IS box-tested on pop  blas.rs:262-264
-                sp += 1u;
+                st_put(sp, blas_root);                       // BLAS root IS box-tested on pop  blas.rs:262-264
+                sp += sp_step;
             }
         }
     }
@@ -1313,12 +1358,13 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
                                 const ClosestOut& out)
 {
     const size_t lds = trace_lds_bytes(tl, true);
-    if (tl.lds_scene)
-        hipLaunchKernelGGL((k_closest<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a,
-                           rq.b, n_ptr, head, out);
-    else
-        hipLaunchKernelGGL((k_closest<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a,
-                           rq.b, n_ptr, head, out);
+    const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
+    const dim3 grid(tl.grid_blocks), block(tl.block_threads);
+    const uint4* blob = (const uint4*)tl.blob;
+    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_closest<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
+    else if (tl.lds_scene) hipLaunchKernelGGL((k_closest<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
+    else if (!spill) hipLaunchKernelGGL((k_closest<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
+    else hipLaunchKernelGGL((k_closest<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,

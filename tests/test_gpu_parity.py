@@ -100,6 +100,17 @@ def test_trace_matches_oracle_on_random_rays(api, oracle_mod, scene_name, n):
     O[300:400] = np.round(O[300:400] / 139) * 139           # origins on box planes
     D[400:420, 2] = -0.0
     D[400:420] /= np.linalg.norm(D[400:420], axis=1, keepdims=True)
+    # 0 * inf: origin exactly on a wall / box plane AND a (signed) zero direction component on that axis
+    planes = np.array([-278.0, 278.0, -228.0, 328.0, 0.0, 139.0, -139.0], np.float32)
+    for i in range(420, 720):
+        ax = int(rng.integers(0, 3))
+        O[i, ax] = planes[rng.integers(0, len(planes))]
+        D[i, ax] = rng.choice(np.array([0.0, -0.0], np.float32))
+        if i % 3 == 0:                                      # two zero components: an axis-aligned ray sliding along a plane
+            ax2 = (ax + 1) % 3
+            D[i, ax2] = rng.choice(np.array([0.0, -0.0], np.float32))
+        nrm = np.linalg.norm(D[i].astype(np.float64))
+        D[i] = (D[i] / nrm).astype(np.float32)
     for which in (0, 1):
         g = r.trace_closest(O, D, which=which)
         c = o.trace_closest(O, D, which=which)

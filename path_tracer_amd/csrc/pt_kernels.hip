@@ -367,7 +367,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     bool active = false, pending = false, ray_finite = false;
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
-    float t_max = 0.0f, bt = 0.0f, bu = 0.0f, bv = 0.0f;
+    float t_max = 0.0f, bt = 0.0f;
+    float hud = 0.0f, hvd = 0.0f, hdet = 1.0f; // best hit's (u, v) numerators and determinant: divided once, when the ray retires (primitive.rs:158-160)
     uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0;
     bool in_blas = false;
     bool any_phase = false;   // CLOSEST_LIGHTS: the lights-TLAS hit exists, now any-hit against the world (integrator.rs:103)
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     }
                     if (pending)
                     {
-                        out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                        out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
                         const uint32_t k = staged + mbcnt64(qm);
                         const uint32_t cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
                         stage_idx[k] = make_uint2(ray_idx | (cls << 29), pid);
@@ -470,12 +471,12 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     if (pending)
                     {
                         out.occl_b[pid] = chain_code;
-                        if (chain_code == 0u) out.hits[pid] = f4{bt, bu, bv, asf(bid)}; // only a visible light is ever read back
+                        if (chain_code == 0u) out.hits[pid] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
                     }
                 }
                 else
                 {
-                    if (pending) out.hits[ray_idx] = f4{bt, bu, bv, asf(bid)};
+                    if (pending) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
                 }
                 pending = false;
             }
@@ -511,8 +512,9 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 any_phase = false;
                 chain_code = 2u;
                 bt = asf(0x7f800000u);
-                bu = 0.0f;
-                bv = 0.0f;
+                hud = 0.0f;
+                hvd = 0.0f;
+                hdet = 1.0f;
                 in_blas = false;
                 sp = stk.empty();
                 // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
@@ -632,8 +634,9 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     {
                         // primitive.rs:158-170: (t,u,v) = xyz / det ; t += t_estimate
                         bt = td / det + t_est;
-                        bu = ud / det;
-                        bv = vd / det;
+                        hud = ud;
+                        hvd = vd;
+                        hdet = det;
                         t_max = bt;
                         bid = (inst << prim_bits) | (a + k);
                         if (bt != bt) { sp = stk.empty(); in_blas = false; break; } // NaN t_max: nothing else can be accepted

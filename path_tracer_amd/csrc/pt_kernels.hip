@@ -604,8 +604,24 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             const uint2 e = stk.get(sp);
             if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
             const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
-            const uint32_t a = nw[3];
+            uint32_t a = nw[3];
             uint32_t b = nw[7];
+            float t_est = asf(e.y);
+            if ((b >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+            {
+                // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99.  BLAS::intersect pushes its root
+                // with t_enter = 0 and no box test (blas.rs:217) and pops it at once: that pop happens here, in the same step.
+                uint32_t blas_root;
+                ob = to_object(bl, a, w, ray_finite, blas_root);
+                inst = a;
+                in_blas = true;
+                blas_base = sp;
+                if (0.0f > t_max) continue;                  // the root's pop test  blas.rs:222-225
+                nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root);
+                a = nw[3];
+                b = nw[7];
+                t_est = 0.0f;
+            }
             const uint32_t kind = b >> NODE_KIND_SHIFT;
             b &= NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
@@ -623,9 +639,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 if (hl && hr) { stk.put(sp, left_near ? re : le); sp = stk.up(sp); }
                 if (hl || hr) { stk.put(sp, (hl && (left_near || !hr)) ? le : re); sp = stk.up(sp); }
             }
-            else if (kind == NODE_TRIS)
+            else
             {
-                const float t_est = asf(e.y);
                 for (uint32_t k = 0; k < b; ++k)             // blas.rs:230-251
                 {
                     const uint4* tp = bl.tris + 3u * (a + k);
@@ -642,17 +657,6 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         if (bt != bt) { sp = stk.empty(); in_blas = false; break; } // NaN t_max: nothing else can be accepted
                     }
                 }
-            }
-            else
-            {
-                // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99
-                uint32_t blas_root;
-                ob = to_object(bl, a, w, ray_finite, blas_root);
-                inst = a;
-                in_blas = true;
-                blas_base = sp;
-                stk.put(sp, make_uint2(blas_root, 0u)); // root pushed without a box test  blas.rs:217
-                sp = stk.up(sp);
             }
         }
     }

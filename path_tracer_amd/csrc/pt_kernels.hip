@@ -289,10 +289,11 @@ struct ClosestOut
     uint32_t* n_valid;     // rays actually traced (the queue counter counts slots, holes included)
     // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
     uint32_t world_root;
-    uint32_t* occl_b;
+    DPathAux* aux;
+    uint8_t* occl;
     // CLOSEST_PRIMARY
     f3 eye;
-    f4* acc;
+    f4* radiance;
     f4* first_pos;
     uint32_t* first_id;
     uint32_t keep_id_from, keep_pos_from; // path ids at or above these still need first_id / first_pos (last samples of the batch)
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
                         if (missed)
                         {
-                            out.acc[ray_idx] = f4{0.006f, 0.006f, 0.006f, asf(0u)};
+                            out.radiance[ray_idx] = f4{0.006f, 0.006f, 0.006f, 0.0f};
                             if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
                             if (ray_idx >= out.keep_pos_from)
                             {
@@ -470,8 +471,8 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 {
                     if (pending)
                     {
-                        out.occl_b[pid] = chain_code;
-                        if (chain_code == 0u) out.hits[pid] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
+                        out.occl[2u * (size_t)pid + 1u] = (uint8_t)chain_code;
+                        if (chain_code == 0u) out.aux[pid].lhit = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
                     }
                 }
                 else
@@ -706,6 +707,11 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     LaneRay w{}, ob{};
     float t_max = 0.0f;
     uint32_t sp = sp_empty, blas_base = 0;
+    // ANY_SHADOW: `occluded` is PathState::occl (byte pairs by path id, this is byte 0); ANY_HOOK: one word per ray
+    auto put_result = [&](uint32_t v) {
+        if (MODE == ANY_SHADOW) reinterpret_cast<uint8_t*>(occluded)[2u * (size_t)out_idx] = (uint8_t)v;
+        else occluded[out_idx] = v;
+    };
     bool in_blas = false;
     const uint32_t chunk = fetch_chunk_size(n);
     WaveRange wr = first_range(n, chunk);
@@ -743,7 +749,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                         in_blas = false;
                         active = true;
                     }
-                    else { occluded[out_idx] = 0u; } // NaN t_max: every reference box test fails -> not occluded
+                    else { put_result(0u); } // NaN t_max: every reference box test fails -> not occluded
                 }
                 } // not a hole
             }
@@ -759,7 +765,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
             if (sp == sp_empty)
             {
                 active = false;
-                occluded[out_idx] = 0u;
+                put_result(0u);
                 continue;
             }
             sp -= sp_step;
@@ -785,7 +791,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                     if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
                     {
                         active = false;
-                        occluded[out_idx] = 1u;
+                        put_result(1u);
                         break;
                     }
                 }
@@ -893,21 +899,23 @@ __device__ __forceinline__ f3 hit_normal(const SceneView& sv, uint32_t inst, uin
 }
 
 // add the previous bounce's direct-light estimate: accumulated += path_weight * (explicit + bsdf)   integrator.rs:231-234
-__device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& io, uint32_t pid, f3& acc, uint32_t& flags)
+__device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& io, uint32_t pid, const DPathRec& rec, f3& acc, uint32_t& flags)
 {
     if (!(flags & FLAG_NEE_PENDING)) return;
-    const f4 e4 = io.st.nee_e[pid];
-    const f4 pw4 = io.st.nee_pw[pid];
+    const f4 e4 = rec.nee_e;
+    const f4 pw4 = rec.nee_pw;
+    const DPathAux* const aux = io.st.aux + pid;
     f3 e = xyz(e4);
-    if (io.st.occl_e[pid] != 0u) e = f3{0.0f, 0.0f, 0.0f};               // integrator.rs:55-56,73
+    const uchar2 oc = *reinterpret_cast<const uchar2*>(io.st.occl + 2u * (size_t)pid);
+    if (oc.x != 0u) e = f3{0.0f, 0.0f, 0.0f};               // integrator.rs:55-56,73
     f3 s{0.0f, 0.0f, 0.0f};
     if (flags & FLAG_BSDF_CAST)
     {
-        if (io.st.occl_b[pid] == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
+        if (oc.y == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
         {
-            const f4 lh = io.st.lhit[pid];
+            const f4 lh = aux->lhit;
             const uint32_t lid = asu(lh.w);
-            const f4 b4 = io.st.nee_b[pid];
+            const f4 b4 = aux->nee_b;
             const uint32_t inst = lid >> sv.prim_bits, tri = lid & ((1u << sv.prim_bits) - 1u);
             const DInstance& in = sv.instances[inst];
             const DMaterial& lm = sv.materials[in.material];
@@ -954,14 +962,15 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
         uint32_t flags = 0u;
         if (bounce != 0u)
         {
-            const f4 acc4 = io.st.acc[pid];
+            const DPathRec& rec = io.st.rec[pid];
+            const f4 acc4 = rec.acc;
             acc = xyz(acc4);
             flags = asu(acc4.w);
-            resolve_nee(sv, io, pid, acc, flags);
+            resolve_nee(sv, io, pid, rec, acc, flags);
         }
         if (!dead)
         {
-            const f3 pw = bounce == 0u ? f3{1.0f, 1.0f, 1.0f} : xyz(io.st.pw[pid]);
+            const f3 pw = bounce == 0u ? f3{1.0f, 1.0f, 1.0f} : xyz(io.st.rec[pid].pw);
             const uint32_t hid = asu(hit.w);
             if (hid == MISS_ID)
             {
@@ -986,7 +995,7 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
                     acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
             }
         }
-        io.st.acc[pid] = f4{acc.x, acc.y, acc.z, asf(flags)};
+        io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // every entry of this queue is a finished path
     }
 }
 
@@ -1022,11 +1031,12 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             flags = 0u;
             if (bounce != 0u)
             {
-                const f4 acc4 = io.st.acc[pid];
-                pw4 = io.st.pw[pid];
+                const DPathRec& rec = io.st.rec[pid];
+                const f4 acc4 = rec.acc;
+                pw4 = rec.pw;
                 acc = xyz(acc4);
                 flags = asu(acc4.w);
-                resolve_nee(sv, io, pid, acc, flags);
+                resolve_nee(sv, io, pid, rec, acc, flags);
             }
             pw = xyz(pw4);
 
@@ -1240,13 +1250,18 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
         if (valid)
         {
-            io.st.pw[pid] = f4{pw.x, pw.y, pw.z, asf(draws)};
-            io.st.acc[pid] = f4{acc.x, acc.y, acc.z, asf(flags)};
-            if (flags & FLAG_NEE_PENDING)
+            if (!want_next && !want_dead) io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // the path ended here, nothing owed
+            else
             {
-                io.st.nee_e[pid] = nee_e;
-                io.st.nee_pw[pid] = nee_pw;
-                if (flags & FLAG_BSDF_CAST) io.st.nee_b[pid] = nee_b;
+                DPathRec& rec = io.st.rec[pid];
+                rec.pw = f4{pw.x, pw.y, pw.z, asf(draws)};
+                rec.acc = f4{acc.x, acc.y, acc.z, asf(flags)};
+                if (flags & FLAG_NEE_PENDING)
+                {
+                    rec.nee_e = nee_e;
+                    rec.nee_pw = nee_pw;
+                    if (flags & FLAG_BSDF_CAST) io.st.aux[pid].nee_b = nee_b;
+                }
             }
         }
     }
@@ -1276,7 +1291,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
     for (uint32_t s = 0; s < rp.batch_samples; ++s)
     {
         const uint32_t pid = s * rp.local_pixels + lp;
-        const f3 c = finalise(xyz(st.acc[pid]));
+        const f3 c = finalise(xyz(st.radiance[pid]));
         a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
         // (id << 16) | new once per sample: only the last two samples survive in 32 bits
         if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
@@ -1290,7 +1305,7 @@ __global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, co
 {
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= rp.n_paths) return;
-    const f3 c = finalise(xyz(st.acc[pid]));
+    const f3 c = finalise(xyz(st.radiance[pid]));
     out[pid] = f4{c.x, c.y, c.z, 1.0f};
 }
 
@@ -1400,7 +1415,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     if (b == 0u)
     {
         out.eye = f3{cam.eye[0], cam.eye[1], cam.eye[2]};
-        out.acc = wb.st.acc;
+        out.radiance = wb.st.radiance;
         out.first_pos = wb.st.first_pos;
         out.first_id = wb.st.first_id;
         out.keep_id_from = rp.keep_id_from;
@@ -1414,18 +1429,19 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, wb.st.occl_e, &row->valid_shadow);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.occl), &row->valid_shadow);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
     ClosestOut out{};
-    out.hits = wb.st.lhit;
+    out.hits = nullptr; // the light hit goes to the path's DPathAux
     out.n_shade = nullptr;
     out.n_light_hit = &row->n_lchain_hit;
     out.n_valid = &row->valid_lchain;
     out.world_root = tl.scene.world_root;
-    out.occl_b = wb.st.occl_b;
+    out.aux = wb.st.aux;
+    out.occl = wb.st.occl;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
 }
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,

@@ -143,20 +143,35 @@ struct RenderParams
     uint64_t seed;
 };
 
-// wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel), SoA of 16-byte words
+// wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel).  What a shading pass reads and writes together is
+// ONE 64-byte record: in later bounces only a sparse subset of paths is alive, and a record costs one memory sector per live path
+// where a structure of arrays costs one sector per field.
+struct DPathRec
+{
+    f4 pw;     // path_weight.xyz | draws consumed (bits)
+    f4 acc;    // accumulated.xyz | flags (bits): bit16 last_delta, bit17 nee pending, bit18 bsdf ray cast
+    f4 nee_e;  // explicit-light candidate contribution (integrator.rs:69-70) | slot of the BSDF-sampled ray in rq_lchain (bits)
+    f4 nee_pw; // path_weight at NEE time | bsdf pdf of the BSDF-sampled direction
+};
+// the rarely needed rest
+struct DPathAux
+{
+    f4 nee_b;        // bsdf rgb of the BSDF-sampled direction | weakening
+    f4 lhit;         // lights-TLAS closest hit of the BSDF-sampled ray: t,u,v | id   (written only for a visible light)
+};
+static_assert(sizeof(DPathRec) == 64 && sizeof(DPathAux) == 32, "path state layout");
 struct PathState
 {
-    f4* pw;        // path_weight.xyz | draws consumed (bits)
-    f4* acc;       // accumulated.xyz | flags (bits): [15:0] bounce, bit16 last_delta, bit17 nee pending, bit18 bsdf ray cast
-    f4* nee_e;     // explicit-light candidate contribution (integrator.rs:69-70) | unused
-    f4* nee_pw;    // path_weight at NEE time | bsdf pdf of the BSDF-sampled direction
-    f4* nee_b;     // bsdf rgb of the BSDF-sampled direction | weakening
-    f4* lhit;      // lights-TLAS closest hit of the BSDF-sampled ray: t,u,v | id
-    uint32_t* occl_e; // 1 = explicit shadow ray blocked
-    uint32_t* occl_b; // 1 = BSDF-sampled ray blocked before the light
-    f4* first_pos; // first-hit xyz | t        (main.rs:205)
+    DPathRec* rec;
+    DPathAux* aux;
+    // results of the two NEE traversals of the path's last bounce, written by the traversal kernels: dense 2-byte pairs so that
+    // neighbouring paths' results merge into whole sectors.  [2*pid] = explicit shadow ray blocked (0/1); [2*pid+1] = BSDF-sampled
+    // ray: 0 reached a light, 1 blocked before it, 2 no light on the ray
+    uint8_t* occl;
+    uint32_t* vstack;   // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
+    f4* radiance;       // finished paths: accumulated.xyz (what integrate() returns before the finite check), dense by path id
+    f4* first_pos;      // first-hit xyz | t        (main.rs:205)
     uint32_t* first_id;
-    uint32_t* vstack; // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
 };
 enum : uint32_t { FLAG_BOUNCE_MASK = 0xffffu, FLAG_LAST_DELTA = 1u << 16, FLAG_NEE_PENDING = 1u << 17, FLAG_BSDF_CAST = 1u << 18 };
 

@@ -289,7 +289,6 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
 #define TAKE(ptr, bytes)                                  \
     if ((r = take((bytes), (void**)&(ptr)))) return r;
     TAKE(w.st.rec, n_paths * sizeof(DPathRec));
-    TAKE(w.st.aux, n_paths * sizeof(DPathAux));
     TAKE(w.st.radiance, n_paths * 16);
     TAKE(w.st.occl, n_paths * 2);
     if (c->sv.has_volumes) { TAKE(w.st.vstack, n_paths * 4); }
@@ -302,11 +301,13 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
         TAKE(w.rq[k].b, n_slots * 16);
         TAKE(w.rq_lchain[k].a, n_slots * 16);
         TAKE(w.rq_lchain[k].b, n_slots * 16);
+        TAKE(w.lchain_nb[k], n_slots * 16);
         TAKE(w.q_term[k], n_slots_term * 8);
     }
     TAKE(w.rq_shadow.a, n_slots * 16);
     TAKE(w.rq_shadow.b, n_slots * 16);
     TAKE(w.hits, n_slots * 16);
+    TAKE(w.lchain_hit, n_slots * 16);
     w.q_shade[Q_TERMINAL] = nullptr;
     for (uint32_t q = 1; q < Q_COUNT; ++q)
     {
@@ -491,7 +492,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     if ((r = upload_scene(c))) return r;
     if ((r = ensure_frame(c))) return r;
     // Auto batch: as many samples per pixel resident as HBM allows (fewer, larger launches: the late bounces of a small batch
-    // cannot fill 256 CUs).  ~380 B of wavefront state per path; ray indices are 29-bit.
+    // cannot fill 256 CUs).  ~390 B of wavefront state per path; ray indices are 29-bit.
     size_t max_paths = (size_t)96 << 20;
     {
         size_t free_b = 0, total_b = 0;
@@ -499,7 +500,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         {
             size_t held = 0;
             for (const DevBuf& b : c->pool) held += b.bytes;
-            max_paths = (size_t)((double)(free_b + held) * 0.75 / 380.0);
+            max_paths = (size_t)((double)(free_b + held) * 0.75 / 390.0);
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }

@@ -22,6 +22,8 @@ struct WavefrontBuffers
     RayQueue rq[2];       // world closest-hit rays, double buffered by bounce parity
     RayQueue rq_shadow;   // explicit-light shadow rays
     RayQueue rq_lchain[2]; // BSDF-sampled NEE rays, double buffered by bounce parity (the next shading pass re-reads directions)
+    f4* lchain_nb[2];     // per BSDF-sampled ray, same slots and parity: bsdf rgb of the sampled direction | weakening
+    f4* lchain_hit;       // per BSDF-sampled ray: its lights-TLAS closest hit t,u,v | id, written only when the light is visible
     f4* hits;             // world closest hits, dense by ray index
     uint2* q_shade[Q_COUNT]; // entries {ray index, path id}; Q_TERMINAL slot unused (see q_term)
     uint2* q_term[2];     // terminal queue {ray index | path id + ENTRY_DEAD, path id}, double buffered by bounce parity

@@ -289,7 +289,6 @@ struct ClosestOut
     uint32_t* n_valid;     // rays actually traced (the queue counter counts slots, holes included)
     // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
     uint32_t world_root;
-    DPathAux* aux;
     uint8_t* occl;
     // CLOSEST_PRIMARY
     f3 eye;
@@ -472,7 +471,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     if (pending)
                     {
                         out.occl[2u * (size_t)pid + 1u] = (uint8_t)chain_code;
-                        if (chain_code == 0u) out.aux[pid].lhit = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
+                        if (chain_code == 0u) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
                     }
                 }
                 else
@@ -868,6 +867,9 @@ struct ShadeIO
 {
     PathState st;
     RayQueue rq_in, rq_out, rq_shadow, rq_lchain_prev, rq_lchain;
+    f4* lchain_nb;            // this bounce's BSDF-sampled rays: bsdf rgb | weakening, by rq_lchain slot
+    const f4* lchain_nb_prev; // last bounce's
+    const f4* lchain_hit;     // last bounce's light hits, by rq_lchain_prev slot
     const f4* hits;
     const uint2* entries;
     uint2* q_term_next;
@@ -904,7 +906,6 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
     if (!(flags & FLAG_NEE_PENDING)) return;
     const f4 e4 = rec.nee_e;
     const f4 pw4 = rec.nee_pw;
-    const DPathAux* const aux = io.st.aux + pid;
     f3 e = xyz(e4);
     const uchar2 oc = *reinterpret_cast<const uchar2*>(io.st.occl + 2u * (size_t)pid);
     if (oc.x != 0u) e = f3{0.0f, 0.0f, 0.0f};               // integrator.rs:55-56,73
@@ -913,9 +914,10 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
     {
         if (oc.y == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
         {
-            const f4 lh = aux->lhit;
+            const uint32_t slot = asu(e4.w); // of the BSDF-sampled ray in last bounce's rq_lchain
+            const f4 lh = io.lchain_hit[slot];
             const uint32_t lid = asu(lh.w);
-            const f4 b4 = aux->nee_b;
+            const f4 b4 = io.lchain_nb_prev[slot];
             const uint32_t inst = lid >> sv.prim_bits, tri = lid & ((1u << sv.prim_bits) - 1u);
             const DInstance& in = sv.instances[inst];
             const DMaterial& lm = sv.materials[in.material];
@@ -923,7 +925,7 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
             const DTriIsect ti = sv.tri_isect[tri];
             const float area = 0.5f * len3(xyz(ti.n0));                    // primitive.rs:94
             const float sample_pdf = (area * len3(emitted) / sv.light_weight_sum) / area; // light_sampler.rs:39, integrator.rs:111
-            const f3 dir = xyz(io.rq_lchain_prev.b[asu(e4.w)]);
+            const f3 dir = xyz(io.rq_lchain_prev.b[slot]);
             bool ff;
             const f3 ln = hit_normal(sv, inst, tri, lh.y, lh.z, dir, ff);
             const float cosine = fabsf(dot3(dir, ln));
@@ -1245,7 +1247,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint32_t pos[4];
         block_append4(sh_append, ctrs, preds, rsize, pos);
         if (want_shadow) { io.rq_shadow.a[pos[0]] = sh_a; io.rq_shadow.b[pos[0]] = sh_b; }
-        if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; nee_e.w = asf(pos[1]); }
+        if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
         if (want_next) { io.rq_out.a[pos[2]] = nx_a; io.rq_out.b[pos[2]] = nx_b; }
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
         if (valid)
@@ -1260,7 +1262,6 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
                 {
                     rec.nee_e = nee_e;
                     rec.nee_pw = nee_pw;
-                    if (flags & FLAG_BSDF_CAST) io.st.aux[pid].nee_b = nee_b;
                 }
             }
         }
@@ -1435,12 +1436,11 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
 {
     Counters* row = wb.counters + b;
     ClosestOut out{};
-    out.hits = nullptr; // the light hit goes to the path's DPathAux
+    out.hits = wb.lchain_hit;
     out.n_shade = nullptr;
     out.n_light_hit = &row->n_lchain_hit;
     out.n_valid = &row->valid_lchain;
     out.world_root = tl.scene.world_root;
-    out.aux = wb.st.aux;
     out.occl = wb.st.occl;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
 }
@@ -1456,6 +1456,9 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.rq_shadow = wb.rq_shadow;
     io.rq_lchain = wb.rq_lchain[b & 1u];
     io.rq_lchain_prev = wb.rq_lchain[(b + 1u) & 1u];
+    io.lchain_nb = wb.lchain_nb[b & 1u];
+    io.lchain_nb_prev = wb.lchain_nb[(b + 1u) & 1u];
+    io.lchain_hit = wb.lchain_hit;
     io.hits = wb.hits;
     io.entries = qclass == Q_TERMINAL ? wb.q_term[b & 1u] : wb.q_shade[qclass];
     io.q_term_next = wb.q_term[(b + 1u) & 1u];

@@ -153,17 +153,10 @@ struct DPathRec
     f4 nee_e;  // explicit-light candidate contribution (integrator.rs:69-70) | slot of the BSDF-sampled ray in rq_lchain (bits)
     f4 nee_pw; // path_weight at NEE time | bsdf pdf of the BSDF-sampled direction
 };
-// the rarely needed rest
-struct DPathAux
-{
-    f4 nee_b;        // bsdf rgb of the BSDF-sampled direction | weakening
-    f4 lhit;         // lights-TLAS closest hit of the BSDF-sampled ray: t,u,v | id   (written only for a visible light)
-};
-static_assert(sizeof(DPathRec) == 64 && sizeof(DPathAux) == 32, "path state layout");
+static_assert(sizeof(DPathRec) == 64, "path state layout");
 struct PathState
 {
     DPathRec* rec;
-    DPathAux* aux;
     // results of the two NEE traversals of the path's last bounce, written by the traversal kernels: dense 2-byte pairs so that
     // neighbouring paths' results merge into whole sectors.  [2*pid] = explicit shadow ray blocked (0/1); [2*pid+1] = BSDF-sampled
     // ray: 0 reached a light, 1 blocked before it, 2 no light on the ray

@@ -686,7 +686,12 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
 // ------------------------------------------------------------------------------------------------ any hit
 enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 
-template <bool LDS_SCENE, int MODE>
+// TLAS::any_intersect / BLAS::any_intersect (tlas.rs:111-144, blas.rs:257-294) pop a node, test ITS box and push both children
+// untested.  The answer is a disjunction over the triangles of every leaf whose box the ray meets, each tested with that
+// box's own entry distance, so neither the visiting order nor the moment a box is tested can change it.  Here a node's box is
+// tested when its parent is expanded (the instance's BLAS root right after the ray transform) and only nodes that were hit go
+// on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
+template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
                                               uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid)
@@ -694,18 +699,14 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    // per-lane stack of node ids, [level][thread] in LDS; sp is the byte offset of the next free slot inside dynamic LDS
-    char* const lds_bytes = reinterpret_cast<char*>(smem);
-    const uint32_t sp_empty = blob_words * 16u + threadIdx.x * 4u, sp_step = blockDim.x * 4u;
-    auto st_get = [&](uint32_t at) { return *reinterpret_cast<const uint32_t*>(lds_bytes + at); };
-    auto st_put = [&](uint32_t at, uint32_t v) { *reinterpret_cast<uint32_t*>(lds_bytes + at) = v; };
+    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv); // entries (node, entry distance of its box)
     const uint32_t n = *n_ptr;
 
     bool active = false, ray_finite = false;
     uint32_t out_idx = 0, valid_rays = 0;
     LaneRay w{}, ob{};
     float t_max = 0.0f;
-    uint32_t sp = sp_empty, blas_base = 0;
+    uint32_t sp = stk.empty(), blas_base = 0;
     // ANY_SHADOW: `occluded` is PathState::occl (byte pairs by path id, this is byte 0); ANY_HOOK: one word per ray
     auto put_result = [&](uint32_t v) {
         if (MODE == ANY_SHADOW) reinterpret_cast<uint8_t*>(occluded)[2u * (size_t)out_idx] = (uint8_t)v;
@@ -740,16 +741,18 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 w.inv = rcp3(w.d);
                 ray_finite = finite3(w.o) && finite3(w.d);
                 t_max = a.w;
+                in_blas = false;
+                sp = stk.empty();
+                // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
+                float te;
+                const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                if (ok)
                 {
-                    if (t_max == t_max)
-                    {
-                        st_put(sp_empty, root);
-                        sp = sp_empty + sp_step;
-                        in_blas = false;
-                        active = true;
-                    }
-                    else { put_result(0u); } // NaN t_max: every reference box test fails -> not occluded
+                    stk.put(sp, make_uint2(root, asu(te)));
+                    sp = stk.up(sp);
+                    active = true;
                 }
+                else put_result(0u);
                 } // not a hole
             }
             act = __ballot(active);
@@ -761,27 +764,44 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
         {
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false;
-            if (sp == sp_empty)
+            if (sp == stk.empty())
             {
                 active = false;
                 put_result(0u);
                 continue;
             }
-            sp -= sp_step;
-            const uint32_t id = st_get(sp);
-            const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
-            float t_enter;
-            const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
-            const bool hit = slab(n0, n1, so, sinv, t_max, t_enter);
-            if (!hit) continue;                              // tlas.rs:118-121 / blas.rs:264
-            const uint32_t a = n0.w, kind = n1.w >> NODE_KIND_SHIFT, b = n1.w & NODE_PAYLOAD_MASK;
+            sp = stk.down(sp);
+            const uint2 e = stk.get(sp);                     // a node whose box the ray meets at distance e.y
+            const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
+            uint32_t a = nw[3];
+            uint32_t b = nw[7];
+            float t_enter = asf(e.y);
+            if ((b >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+            {
+                // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
+                uint32_t blas_root;
+                ob = to_object(bl, a, w, ray_finite, blas_root);
+                in_blas = true;
+                blas_base = sp;
+                if (!slab(bl.nodes[2u * blas_root], bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root);
+                a = nw[3];
+                b = nw[7];
+            }
+            const uint32_t kind = b >> NODE_KIND_SHIFT;
+            b &= NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
             {
-                st_put(sp, a);                               // left then right: right is popped first
-                st_put(sp + sp_step, b);
-                sp += 2u * sp_step;
+                const uint4 l0 = bl.nodes[2u * a], l1 = bl.nodes[2u * a + 1u];
+                const uint4 r0 = bl.nodes[2u * b], r1 = bl.nodes[2u * b + 1u];
+                const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
+                float tl, tr;
+                const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                if (hl) { stk.put(sp, make_uint2(a, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
+                if (hr) { stk.put(sp, make_uint2(b, asu(tr))); sp = stk.up(sp); }
             }
-            else if (kind == NODE_TRIS)
+            else
             {
                 for (uint32_t k = 0; k < b; ++k)             // intersect_bool  primitive.rs:181-189
                 {
@@ -794,15 +814,6 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                         break;
                     }
                 }
-            }
-            else
-            {
-                uint32_t blas_root;
-                ob = to_object(bl, a, w, ray_finite, blas_root);
-                in_blas = true;
-                blas_base = sp;
-                st_put(sp, blas_root);                       // BLAS root IS box-tested on pop  blas.rs:262-264
-                sp += sp_step;
             }
         }
     }
@@ -1364,7 +1375,7 @@ size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
     const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 8 : 0; // per-wave binning stage (k_closest)
-    return blob + (closest ? (size_t)tl.scene.stack_lds * tl.block_threads * 8 : (size_t)tl.scene.stack_entries * tl.block_threads * 4) + stage;
+    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8 + stage;
 }
 
 } // namespace
@@ -1394,12 +1405,13 @@ static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root,
                             uint32_t* occluded, uint32_t* n_valid)
 {
     const size_t lds = trace_lds_bytes(tl, false);
-    if (tl.lds_scene)
-        hipLaunchKernelGGL((k_any<true, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, occluded, n_valid);
-    else
-        hipLaunchKernelGGL((k_any<false, MODE>), dim3(tl.grid_blocks), dim3(tl.block_threads), lds, s, tl.scene, (const uint4*)tl.blob, root, rq.a, rq.b,
-                           n_ptr, head, occluded, n_valid);
+    const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
+    const dim3 grid(tl.grid_blocks), block(tl.block_threads);
+    const uint4* blob = (const uint4*)tl.blob;
+    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_any<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
+    else if (tl.lds_scene) hipLaunchKernelGGL((k_any<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
+    else if (!spill) hipLaunchKernelGGL((k_any<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
+    else hipLaunchKernelGGL((k_any<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
 }
 
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,

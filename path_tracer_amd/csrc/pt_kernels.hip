@@ -16,8 +16,14 @@
 namespace pt {
 namespace {
 
-constexpr int kStepsPerRound = 6;  // traversal steps between refill checks
-constexpr int kRefillBelow = 40;   // refill idle lanes when at most this many lanes are still traversing
+#ifndef PT_STEPS_PER_ROUND
+#define PT_STEPS_PER_ROUND 8
+#endif
+#ifndef PT_REFILL_BELOW
+#define PT_REFILL_BELOW 40
+#endif
+constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
+constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)

@@ -1,19 +1,20 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/<tag>_*: one kernel-trace pass of the default bench step and separate --pmc passes (never
-# combined with other trace domains).  Run on the GPU box:  bash tools/profile.sh   then  python tools/profile_summary.py gpurun_out/prof <tag>
+# combined with other trace domains; FETCH_SIZE and WRITE_SIZE each need a pass of their own on gfx950).  Run on the GPU box:  bash tools/profile.sh   then  python tools/profile_summary.py gpurun_out/prof <tag>
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O" && mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o r1 -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$O/kt.log" 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o r1 -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$O/kt.log" 2>&1
 echo "kernel trace done"
 i=1
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU" \
-           "FETCH_SIZE WRITE_SIZE" \
+           "FETCH_SIZE" \
+           "WRITE_SIZE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
-    rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o r1 -- python "$R/bench.py" --steps 1 --warmup 0 --spp 43 --no-cpu-baseline > "$O/pmc$i.log" 2>&1
+    timeout -k 5 300 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o r1 -- python "$R/bench.py" --steps 1 --warmup 0 --spp 43 --no-cpu-baseline > "$O/pmc$i.log" 2>&1
     echo "pmc pass $i done"
     i=$((i + 1))
 done

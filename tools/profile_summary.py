@@ -58,11 +58,13 @@ def main(src, tag):
     # the dominant kernel is k_closest in its two world modes (PRIMARY = bounce 0, WORLD = later bounces): bytes per traced ray
     try:
         bench = None
-        for ln in open(os.path.join(src, "pmc3.log")):
-            if ln.startswith("{"):
-                bench = json.loads(ln)
+        for name in sorted(os.listdir(src)):
+            if name.startswith("pmc") and name.endswith(".log"):
+                for ln in open(os.path.join(src, name)):
+                    if ln.startswith("{"):
+                        bench = json.loads(ln)
         rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]
-        keys = [k for k in traffic if k.startswith("k_closest<") and (k.endswith(", 0>") or k.endswith(", 3>"))]
+        keys = [k for k in traffic if re.match(r"k_closest<\w+, [03](, \w+)?>$", k)]
         tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
         traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays,
                                       "note": "PMC passes at batch 43 spp; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read"}

@@ -470,7 +470,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
             if (k.n_shade[q] > c->cap_slots) return fail(c, PT_ERR_LIMIT, "internal: shade queue reservation exceeded its capacity");
         c->stats.rays_closest += k.valid_closest;
         c->stats.rays_any += (uint64_t)k.valid_shadow + k.n_lchain_hit;
-        c->stats.rays_light_closest += k.valid_lchain;
+        c->stats.rays_light_closest += (uint64_t)k.valid_lchain + k.culled_lchain; // casts of integrator.rs:100, whoever answered them
     }
     c->stats.paths += rp.n_paths;
     harvest_events(c);

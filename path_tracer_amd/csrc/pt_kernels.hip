@@ -1027,6 +1027,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
     const uint32_t n = io.ctr->n_shade[QCLASS];
     const uint32_t rsize = region_size(n, gridDim.x);
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
+    uint32_t culled = 0;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
     {
         bool valid = idx < n;
@@ -1213,12 +1214,22 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
                     if (dot3(dir, normal) > 0.0f)                                      // integrator.rs:96
                     {
                         const BsdfSample bp = mat_bsdf_pdf(mat, wi, dir, normal, front);
-                        nee_b = f4{bp.bsdf.x, bp.bsdf.y, bp.bsdf.z, mat_weakening(mat.kind, dir, normal)};
-                        nee_pw.w = bp.pdf;
-                        want_lchain = true;
-                        lc_a = f4{p.x, p.y, p.z, asf(0x7f800000u)};
-                        lc_b = f4{dir.x, dir.y, dir.z, asf(pid)};
-                        flags |= FLAG_BSDF_CAST;
+                        // scene.lights.intersect(ray) starts with the root box of the lights TLAS (tlas.rs:68-74).  That test is done
+                        // here, with the very arithmetic k_closest uses at refill: a ray that fails it (nearly all of them: the lights
+                        // are small) finds no light, contributes nothing (integrator.rs:100-102) and never becomes a queue entry.
+                        float te;
+                        const uint4* const lr = reinterpret_cast<const uint4*>(sv.nodes + sv.lights_root);
+                        const bool may_hit = slab(lr[0], lr[1], p, rcp3(dir), asf(0x7f800000u), te);
+                        if (may_hit)
+                        {
+                            nee_b = f4{bp.bsdf.x, bp.bsdf.y, bp.bsdf.z, mat_weakening(mat.kind, dir, normal)};
+                            nee_pw.w = bp.pdf;
+                            want_lchain = true;
+                            lc_a = f4{p.x, p.y, p.z, asf(0x7f800000u)};
+                            lc_b = f4{dir.x, dir.y, dir.z, asf(pid)};
+                            flags |= FLAG_BSDF_CAST;
+                        }
+                        else culled += 1u;
                     }
                 }
                 nee_pw.x = pw.x; nee_pw.y = pw.y; nee_pw.z = pw.z;
@@ -1282,6 +1293,11 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
                 }
             }
         }
+    }
+    {
+        uint32_t t = culled;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (t != 0u && lane_id() == 0u) atomicAdd(&io.ctr->culled_lchain, t);
     }
     // hand back what is left of this workgroup's regions as holes (ray queues: path id = HOLE)
     const f4 hole_b{0.0f, 0.0f, 0.0f, asf(HOLE)};

@@ -96,7 +96,7 @@ struct Counters
     uint32_t n_shade[Q_COUNT];
     uint32_t valid_closest;  // world closest-hit rays actually traced
     uint32_t valid_shadow;   // explicit-light shadow rays actually traced
-    uint32_t pad;
+    uint32_t culled_lchain;  // BSDF-sampled NEE rays that miss the lights TLAS's root box: cast (integrator.rs:100) and answered in the shading pass
 };
 static_assert(sizeof(Counters) == 64, "");
 

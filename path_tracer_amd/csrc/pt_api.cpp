@@ -390,6 +390,9 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     rp.keep_id_from = count >= 2 ? (count - 2) * c->local_pixels : 0u;
     rp.keep_pos_from = (count - 1) * c->local_pixels;
     rp.seed = g.seed;
+    rp.div_local_pixels = fastdiv_make(rp.local_pixels);
+    rp.div_width = fastdiv_make(rp.width);
+    rp.div_strip_rows = fastdiv_make(rp.strip_rows);
     const uint32_t rows = g.max_bounces + 2;
     hipStream_t s = c->stream;
     const WavefrontBuffers& wb = c->wb;

@@ -832,17 +832,25 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
 }
 
 // ------------------------------------------------------------------------------------------------ path bookkeeping
-struct PixelId { uint32_t gpixel, sample, lpixel; };
+struct PixelId { uint32_t gpixel, sample, lpixel, gx, gy; };
 
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f)
+{
+    const uint32_t q = __umulhi(f.magic, n);
+    const uint32_t t = ((n - q) >> 1) + q;
+    return f.one ? n : (t >> f.shift);
+}
 __device__ __forceinline__ uint32_t global_row(const RenderParams& rp, uint32_t ly)
 {
-    return ((ly / rp.strip_rows) * rp.world_size + rp.rank) * rp.strip_rows + (ly % rp.strip_rows);
+    const uint32_t strip = fastdiv(ly, rp.div_strip_rows);
+    return (strip * rp.world_size + rp.rank) * rp.strip_rows + (ly - strip * rp.strip_rows);
 }
 __device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t pid)
 {
-    const uint32_t s = pid / rp.local_pixels, lp = pid - s * rp.local_pixels;
-    const uint32_t ly = lp / rp.width, x = lp - ly * rp.width;
-    return PixelId{global_row(rp, ly) * rp.width + x, rp.first_sample + s, lp};
+    const uint32_t s = fastdiv(pid, rp.div_local_pixels), lp = pid - s * rp.local_pixels;
+    const uint32_t ly = fastdiv(lp, rp.div_width), x = lp - ly * rp.width;
+    const uint32_t gy = global_row(rp, ly);
+    return PixelId{gy * rp.width + x, rp.first_sample + s, lp, x, gy};
 }
 
 // main.rs:186-199
@@ -857,9 +865,8 @@ __global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const C
     float jx, jy;
     ss_sobol(rp.n_sobol, px.sample, seed, &jx, &jy);                       // main.rs:194
     const float ox = jx - 0.5f, oy = jy - 0.5f;
-    const uint32_t gx = px.gpixel % rp.width, gy = px.gpixel / rp.width;
-    const float u = ((float)gx + ox) / (float)rp.width;                    // main.rs:196
-    const float v = ((float)gy + oy) / (float)rp.height;                   // main.rs:197
+    const float u = ((float)px.gx + ox) / (float)rp.width;                 // main.rs:196
+    const float v = ((float)px.gy + oy) / (float)rp.height;                // main.rs:197
     // Camera::create_ray  camera.rs:94-105  (Mat4::project_point3, then normalise)
     const float nx = u * 2.0f - 1.0f, ny = v * 2.0f - 1.0f, nz = 0.0f;
     const float* M = cam.ray_matrix;

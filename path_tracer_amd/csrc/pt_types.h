@@ -128,6 +128,30 @@ struct CameraView
     float pad;
 };
 
+// Division by a launch-invariant divisor (Granlund-Montgomery / libdivide "branch-free" form): n / d = (((n - q) >> 1) + q) >> shift
+// with q = mulhi(magic, n), exact for every 32-bit n and d >= 2; d == 1 is flagged.  Built on the host (fastdiv_make).
+struct FastDiv
+{
+    uint32_t magic, shift, one, d;
+};
+inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f{0u, 0u, d <= 1u ? 1u : 0u, d};
+    if (d <= 1u) return f;
+    uint32_t l = 31u;
+    while (!((d >> l) & 1u)) --l;                 // floor(log2 d)
+    if ((d & (d - 1u)) == 0u) { f.magic = 0u; f.shift = l - 1u; return f; }
+    const uint64_t num = (uint64_t)1 << (32u + l);
+    uint64_t m = num / d;
+    const uint64_t rem = num - m * d;
+    m += m;
+    const uint64_t twice_rem = rem + rem;
+    if (twice_rem >= d) m += 1u;
+    f.magic = (uint32_t)(m + 1u);
+    f.shift = l;
+    return f;
+}
+
 struct RenderParams
 {
     uint32_t width, height;
@@ -141,6 +165,7 @@ struct RenderParams
     uint32_t keep_pos_from;  // path ids >= this belong to the batch's last sample (first-hit position, main.rs:205)
     uint32_t pad;
     uint64_t seed;
+    FastDiv div_local_pixels, div_width, div_strip_rows;
 };
 
 // wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel).  What a shading pass reads and writes together is

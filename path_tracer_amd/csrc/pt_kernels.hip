@@ -22,7 +22,11 @@ namespace {
 #ifndef PT_REFILL_BELOW
 #define PT_REFILL_BELOW 40
 #endif
+#ifndef PT_STEPS_ANY
+#define PT_STEPS_ANY PT_STEPS_PER_ROUND
+#endif
 constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
+constexpr int kStepsAny = PT_STEPS_ANY;
 constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -766,7 +770,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
         }
 
 #pragma unroll 1
-        for (int it = 0; it < kStepsPerRound; ++it)
+        for (int it = 0; it < kStepsAny; ++it)
         {
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false;

@@ -159,10 +159,12 @@ int upload_scene(pt_ctx* c)
     if (r) return r;
     const FlatScene& f = c->scene.flat;
     const size_t nb = f.nodes.size() * sizeof(DNode), tb = f.tri_isect.size() * sizeof(DTriIsect), ib = f.instances.size() * sizeof(DInstance);
-    std::vector<uint8_t> blob(nb + tb + ib);
+    const size_t lb = (f.big_leaves.size() * 4 + 15) / 16 * 16; // big-leaf table {first, count}, usually empty
+    std::vector<uint8_t> blob(nb + tb + ib + lb);
     std::memcpy(blob.data(), f.nodes.data(), nb);
     std::memcpy(blob.data() + nb, f.tri_isect.data(), tb);
     std::memcpy(blob.data() + nb + tb, f.instances.data(), ib);
+    if (lb) std::memcpy(blob.data() + nb + tb + ib, f.big_leaves.data(), f.big_leaves.size() * 4);
     if ((r = dev_alloc(c, c->d_blob, blob.size()))) return r;
     HIPCHK(c, hipMemcpy(c->d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {

@@ -220,7 +220,14 @@ struct Blob
     const uint4* nodes; // 2 words per node
     const uint4* tris;  // 3 words per triangle
     const uint4* inst;  // 7 words per instance
+    const uint2* leaves; // big-leaf table {first, count} (NODE_TRIS_BIG)
 };
+// triangles of a leaf link
+__device__ __forceinline__ void leaf_range(const Blob& bl, uint32_t kind, uint32_t payload, uint32_t& first, uint32_t& count)
+{
+    if (kind == NODE_TRIS) { first = payload & LEAF_FIRST_MASK; count = (payload >> LEAF_FIRST_BITS) + 1u; }
+    else { const uint2 lf = bl.leaves[payload]; first = lf.x; count = lf.y; }
+}
 
 struct LaneRay { f3 o, d, inv; };
 
@@ -275,6 +282,7 @@ __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __
         b.nodes = smem;
         b.tris = smem + 2u * sv.n_nodes;
         b.inst = smem + 2u * sv.n_nodes + 3u * sv.n_tris;
+        b.leaves = reinterpret_cast<const uint2*>(smem + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
     }
     else
     {
@@ -282,6 +290,7 @@ __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __
         b.nodes = gblob;
         b.tris = gblob + 2u * sv.n_nodes;
         b.inst = gblob + 2u * sv.n_nodes + 3u * sv.n_tris;
+        b.leaves = reinterpret_cast<const uint2*>(gblob + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
     }
     return b;
 }
@@ -529,10 +538,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 sp = stk.empty();
                 // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
                 float te;
-                const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[2u * root];
+                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
-                    stk.put(sp, make_uint2(root, 0u));
+                    stk.put(sp, make_uint2(root0.w, 0u));    // entries are (link, t_enter); the root goes in with t_enter 0
                     sp = stk.up(sp);
                     active = true;
                 }
@@ -550,28 +560,42 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
             if (MODE == CLOSEST_LIGHTS && any_phase)
             {
-                // TLAS::any_intersect on the world with t_max = light_t * (1 - EPS)   tlas.rs:111-144, blas.rs:257-294
+                // TLAS::any_intersect on the world with t_max = light_t * (1 - EPS)   tlas.rs:111-144, blas.rs:257-294; entries are
+                // (link, entry distance) of nodes whose box was already met, as in k_any
                 if (sp == stk.empty()) { active = false; pending = true; chain_code = 0u; continue; }
                 sp = stk.down(sp);
-                const uint32_t id = stk.get(sp).x;
-                const uint4 n0 = bl.nodes[2u * id], n1 = bl.nodes[2u * id + 1u];
-                float t_enter;
-                const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
-                const bool hit = slab(n0, n1, so, sinv, t_max, t_enter);
-                if (!hit) continue;
-                const uint32_t ka = n0.w, kkind = n1.w >> NODE_KIND_SHIFT, kb = n1.w & NODE_PAYLOAD_MASK;
+                const uint2 e = stk.get(sp);
+                uint32_t link = e.x;
+                float t_enter = asf(e.y);
+                if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+                {
+                    uint32_t blas_root;
+                    ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
+                    in_blas = true;
+                    blas_base = sp;
+                    const uint4 r0 = bl.nodes[2u * blas_root];
+                    if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                    link = r0.w;
+                }
+                const uint32_t kkind = link >> NODE_KIND_SHIFT, kpay = link & NODE_PAYLOAD_MASK;
                 if (kkind == NODE_BRANCH)
                 {
-                    stk.put(sp, make_uint2(ka, 0u));
-                    sp = stk.up(sp);
-                    stk.put(sp, make_uint2(kb, 0u));
-                    sp = stk.up(sp);
+                    const uint4* cp = bl.nodes + 2u * kpay;
+                    const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
+                    const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
+                    float tl, tr;
+                    const bool hl = slab(l0, l1, so, sinv, t_max, tl);
+                    const bool hr = slab(r0, r1, so, sinv, t_max, tr);
+                    if (hl) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }
+                    if (hr) { stk.put(sp, make_uint2(r0.w, asu(tr))); sp = stk.up(sp); }
                 }
-                else if (kkind == NODE_TRIS)
+                else
                 {
-                    for (uint32_t k = 0; k < kb; ++k)
+                    uint32_t first, count;
+                    leaf_range(bl, kkind, kpay, first, count);
+                    for (uint32_t k = 0; k < count; ++k)
                     {
-                        const uint4* tp = bl.tris + 3u * (ka + k);
+                        const uint4* tp = bl.tris + 3u * (first + k);
                         float td, ud, vd, det;
                         if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
                         {
@@ -581,15 +605,6 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                             break;
                         }
                     }
-                }
-                else
-                {
-                    uint32_t blas_root;
-                    ob = to_object(bl, ka, w, ray_finite, blas_root);
-                    in_blas = true;
-                    blas_base = sp;
-                    stk.put(sp, make_uint2(blas_root, 0u));
-                    sp = stk.up(sp);
                 }
                 continue;
             }
@@ -602,8 +617,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     any_phase = true;
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
-                    if (t_max == t_max) { stk.put(sp, make_uint2(out.world_root, 0u)); sp = stk.up(sp); }
-                    else { active = false; pending = true; chain_code = 0u; } // NaN t_max: every box test fails -> visible
+                    float te = 0.0f;
+                    const uint4 wr0 = bl.nodes[2u * out.world_root];
+                    // NaN t_max: every box test fails -> visible; so does a ray that misses the world's root box (tlas.rs:118-121)
+                    if (t_max == t_max && slab(wr0, bl.nodes[2u * out.world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
+                    else { active = false; pending = true; chain_code = 0u; }
                     continue;
                 }
                 active = false;
@@ -613,47 +631,44 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             sp = stk.down(sp);
             const uint2 e = stk.get(sp);
             if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
-            const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
-            uint32_t a = nw[3];
-            uint32_t b = nw[7];
+            uint32_t link = e.x;
             float t_est = asf(e.y);
-            if ((b >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+            if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
             {
                 // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99.  BLAS::intersect pushes its root
                 // with t_enter = 0 and no box test (blas.rs:217) and pops it at once: that pop happens here, in the same step.
                 uint32_t blas_root;
-                ob = to_object(bl, a, w, ray_finite, blas_root);
-                inst = a;
+                inst = link & NODE_PAYLOAD_MASK;
+                ob = to_object(bl, inst, w, ray_finite, blas_root);
                 in_blas = true;
                 blas_base = sp;
                 if (0.0f > t_max) continue;                  // the root's pop test  blas.rs:222-225
-                nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root);
-                a = nw[3];
-                b = nw[7];
+                link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3];
                 t_est = 0.0f;
             }
-            const uint32_t kind = b >> NODE_KIND_SHIFT;
-            b &= NODE_PAYLOAD_MASK;
+            const uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
             {
-                // push_to_stack  blas.rs:133-162
-                const uint4 l0 = bl.nodes[2u * a], l1 = bl.nodes[2u * a + 1u];
-                const uint4 r0 = bl.nodes[2u * b], r1 = bl.nodes[2u * b + 1u];
+                // push_to_stack  blas.rs:133-162; the children are one contiguous 64-byte record pair
+                const uint4* cp = bl.nodes + 2u * payload;
+                const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);
                 const bool hr = slab(r0, r1, o, inv, t_max, tr);
                 // both hit: the farther child goes underneath (ties: left underneath, right popped first); one hit: that child
                 const bool left_near = tl < tr;
-                const uint2 le = make_uint2(a, asu(tl)), re = make_uint2(b, asu(tr));
+                const uint2 le = make_uint2(l0.w, asu(tl)), re = make_uint2(r0.w, asu(tr));
                 if (hl && hr) { stk.put(sp, left_near ? re : le); sp = stk.up(sp); }
                 if (hl || hr) { stk.put(sp, (hl && (left_near || !hr)) ? le : re); sp = stk.up(sp); }
             }
             else
             {
-                for (uint32_t k = 0; k < b; ++k)             // blas.rs:230-251
+                uint32_t first, count;
+                leaf_range(bl, kind, payload, first, count);
+                for (uint32_t k = 0; k < count; ++k)         // blas.rs:230-251
                 {
-                    const uint4* tp = bl.tris + 3u * (a + k);
+                    const uint4* tp = bl.tris + 3u * (first + k);
                     float td, ud, vd, det;
                     if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_est, td, ud, vd, det))
                     {
@@ -663,7 +678,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         hvd = vd;
                         hdet = det;
                         t_max = bt;
-                        bid = (inst << prim_bits) | (a + k);
+                        bid = (inst << prim_bits) | (first + k);
                         if (bt != bt) { sp = stk.empty(); in_blas = false; break; } // NaN t_max: nothing else can be accepted
                     }
                 }
@@ -755,10 +770,11 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 sp = stk.empty();
                 // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
                 float te;
-                const bool ok = (t_max == t_max) && slab(bl.nodes[2u * root], bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[2u * root];
+                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
-                    stk.put(sp, make_uint2(root, asu(te)));
+                    stk.put(sp, make_uint2(root0.w, asu(te)));
                     sp = stk.up(sp);
                     active = true;
                 }
@@ -781,41 +797,39 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
                 continue;
             }
             sp = stk.down(sp);
-            const uint2 e = stk.get(sp);                     // a node whose box the ray meets at distance e.y
-            const uint32_t* nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * e.x);
-            uint32_t a = nw[3];
-            uint32_t b = nw[7];
+            const uint2 e = stk.get(sp);                     // (link, entry distance) of a node whose box the ray meets
+            uint32_t link = e.x;
             float t_enter = asf(e.y);
-            if ((b >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+            if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
             {
                 // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
                 uint32_t blas_root;
-                ob = to_object(bl, a, w, ray_finite, blas_root);
+                ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
                 in_blas = true;
                 blas_base = sp;
-                if (!slab(bl.nodes[2u * blas_root], bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
-                nw = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root);
-                a = nw[3];
-                b = nw[7];
+                const uint4 r0 = bl.nodes[2u * blas_root];
+                if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                link = r0.w;
             }
-            const uint32_t kind = b >> NODE_KIND_SHIFT;
-            b &= NODE_PAYLOAD_MASK;
+            const uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
             {
-                const uint4 l0 = bl.nodes[2u * a], l1 = bl.nodes[2u * a + 1u];
-                const uint4 r0 = bl.nodes[2u * b], r1 = bl.nodes[2u * b + 1u];
+                const uint4* cp = bl.nodes + 2u * payload;
+                const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);
                 const bool hr = slab(r0, r1, o, inv, t_max, tr);
-                if (hl) { stk.put(sp, make_uint2(a, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
-                if (hr) { stk.put(sp, make_uint2(b, asu(tr))); sp = stk.up(sp); }
+                if (hl) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
+                if (hr) { stk.put(sp, make_uint2(r0.w, asu(tr))); sp = stk.up(sp); }
             }
             else
             {
-                for (uint32_t k = 0; k < b; ++k)             // intersect_bool  primitive.rs:181-189
+                uint32_t first, count;
+                leaf_range(bl, kind, payload, first, count);
+                for (uint32_t k = 0; k < count; ++k)         // intersect_bool  primitive.rs:181-189
                 {
-                    const uint4* tp = bl.tris + 3u * (a + k);
+                    const uint4* tp = bl.tris + 3u * (first + k);
                     float td, ud, vd, det;
                     if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
                     {

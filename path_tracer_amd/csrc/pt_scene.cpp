@@ -494,31 +494,66 @@ int HostScene::flatten(std::string* err)
         d.mn[0] = b.mn.x; d.mn[1] = b.mn.y; d.mn[2] = b.mn.z;
         d.mx[0] = b.mx.x; d.mx[1] = b.mx.y; d.mx[2] = b.mx.z;
     };
-    auto put_tlas = [&](const HostTlas& t, uint32_t base, uint32_t inst_base) {
+    // device order of one tree: breadth-first, the children of a branch in adjacent slots (left, right)
+    auto layout = [](const std::vector<HostNode>& nodes, uint32_t root, uint32_t base, std::vector<uint32_t>& where) -> bool {
+        where.assign(nodes.size(), MISS_ID);
+        if (root == MISS_ID) return nodes.empty();
+        std::vector<uint32_t> order{root};
+        where[root] = base;
+        uint32_t next = base + 1u;
+        for (size_t k = 0; k < order.size(); ++k)
+        {
+            const HostNode& n = nodes[order[k]];
+            if (n.kind != NODE_BRANCH) continue;
+            where[n.a] = next;
+            where[n.b] = next + 1u;
+            next += 2u;
+            order.push_back(n.a);
+            order.push_back(n.b);
+        }
+        return next == base + nodes.size();
+    };
+    auto leaf_link = [&](uint32_t first, uint32_t count) -> uint32_t {
+        if (count >= 1u && count <= LEAF_MAX_COUNT && first <= LEAF_FIRST_MASK)
+            return (NODE_TRIS << NODE_KIND_SHIFT) | ((count - 1u) << LEAF_FIRST_BITS) | first;
+        f.big_leaves.push_back(first);
+        f.big_leaves.push_back(count);
+        return (NODE_TRIS_BIG << NODE_KIND_SHIFT) | (uint32_t)(f.big_leaves.size() / 2u - 1u);
+    };
+    std::vector<uint32_t> slot_of;
+    auto put_tlas = [&](const HostTlas& t, uint32_t base, uint32_t inst_base) -> bool {
+        if (!layout(t.nodes, t.root, base, slot_of)) return false;
         for (size_t i = 0; i < t.nodes.size(); ++i)
         {
-            DNode& d = f.nodes[base + i];
+            DNode& d = f.nodes[slot_of[i]];
             put_box(d, t.nodes[i].box);
-            if (t.nodes[i].kind == NODE_BRANCH) { d.a = base + t.nodes[i].a; d.b = (NODE_BRANCH << NODE_KIND_SHIFT) | (base + t.nodes[i].b); }
-            else { d.a = inst_base + t.nodes[i].a; d.b = (NODE_INSTANCE << NODE_KIND_SHIFT); }
+            if (t.nodes[i].kind == NODE_BRANCH) { d.link = (NODE_BRANCH << NODE_KIND_SHIFT) | slot_of[t.nodes[i].a]; d.aux = slot_of[t.nodes[i].b]; }
+            else { d.link = (NODE_INSTANCE << NODE_KIND_SHIFT) | (inst_base + t.nodes[i].a); d.aux = 0u; }
         }
+        return true;
     };
-    put_tlas(world, world_base, f.inst_base[0]);
-    put_tlas(lights, lights_base, f.inst_base[1]);
-    f.world_root = world.root == MISS_ID ? MISS_ID : world_base + world.root;
-    f.lights_root = lights.root == MISS_ID ? MISS_ID : lights_base + lights.root;
+    if (!put_tlas(world, world_base, f.inst_base[0]) || !put_tlas(lights, lights_base, f.inst_base[1]))
+    {
+        if (err) *err = "internal: TLAS arena holds nodes outside the tree";
+        return -5;
+    }
+    f.world_root = world.root == MISS_ID ? MISS_ID : world_base;   // the root is the first node of its tree
+    f.lights_root = lights.root == MISS_ID ? MISS_ID : lights_base;
 
     uint32_t max_blas_depth = 0;
+    std::vector<uint32_t> blas_root_at(blas.size(), MISS_ID);
     for (size_t i = 0; i < blas.size(); ++i)
     {
         const HostBlas& bl = blas[i];
         max_blas_depth = std::max(max_blas_depth, bl.depth);
+        if (!layout(bl.nodes, bl.root, blas_base[i], slot_of)) { if (err) *err = "internal: BLAS arena holds nodes outside the tree"; return -5; }
+        blas_root_at[i] = blas_base[i];
         for (size_t n = 0; n < bl.nodes.size(); ++n)
         {
-            DNode& d = f.nodes[blas_base[i] + n];
+            DNode& d = f.nodes[slot_of[n]];
             put_box(d, bl.nodes[n].box);
-            if (bl.nodes[n].kind == NODE_BRANCH) { d.a = blas_base[i] + bl.nodes[n].a; d.b = (NODE_BRANCH << NODE_KIND_SHIFT) | (blas_base[i] + bl.nodes[n].b); }
-            else { d.a = f.tri_base[i] + bl.nodes[n].a; d.b = (NODE_TRIS << NODE_KIND_SHIFT) | bl.nodes[n].b; }
+            if (bl.nodes[n].kind == NODE_BRANCH) { d.link = (NODE_BRANCH << NODE_KIND_SHIFT) | slot_of[bl.nodes[n].a]; d.aux = slot_of[bl.nodes[n].b]; }
+            else { d.link = leaf_link(f.tri_base[i] + bl.nodes[n].a, bl.nodes[n].b); d.aux = bl.nodes[n].b; }
         }
         for (uint32_t id : bl.prim_ids) // triangles stored in leaf order
         {
@@ -542,7 +577,7 @@ int HostScene::flatten(std::string* err)
                 const float rows[12] = {x.m.c0.x, x.m.c1.x, x.m.c2.x, x.t.x, x.m.c0.y, x.m.c1.y, x.m.c2.y, x.t.y, x.m.c0.z, x.m.c1.z, x.m.c2.z, x.t.z};
                 std::memcpy(dst[k], rows, sizeof(rows));
             }
-            d.root = blas_base[hi.model] + blas[hi.model].root;
+            d.root = blas_root_at[hi.model];
             d.blas = hi.blas;
             d.material = (uint32_t)blas[hi.model].material;
             switch (materials[d.material].kind)

@@ -75,6 +75,7 @@ struct FlatScene
     std::vector<DTriVerts> tri_shade, tri_pos;
     std::vector<uint32_t> tri_orig;
     std::vector<DInstance> instances;
+    std::vector<uint32_t> big_leaves;   // {first, count} pairs of the leaves NODE_TRIS cannot encode
     std::vector<DMaterial> materials;
     std::vector<DLight> lights;
     std::vector<uint32_t> tri_base;     // per model: absolute index of its first triangle

@@ -19,20 +19,27 @@ namespace pt {
 
 enum : uint32_t
 {
-    NODE_BRANCH = 0u,
-    NODE_TRIS = 1u,
-    NODE_INSTANCE = 2u,
+    NODE_BRANCH = 0u,   // link payload: index of the left child; the right child is the next node
+    NODE_TRIS = 1u,     // link payload: (count - 1) << 24 | first triangle (leaf order)
+    NODE_INSTANCE = 2u, // link payload: instance index
+    NODE_TRIS_BIG = 3u, // link payload: index into the big-leaf table {first, count} (leaves over 64 triangles / scenes over 2^24)
     NODE_KIND_SHIFT = 30u,
     NODE_PAYLOAD_MASK = 0x3fffffffu,
+    LEAF_FIRST_BITS = 24u,
+    LEAF_FIRST_MASK = 0x00ffffffu,
+    LEAF_MAX_COUNT = 64u,
     MISS_ID = 0xffffffffu
 };
 
+// One BVH node.  `link` (kind << 30 | payload) is everything a traversal needs once the node's box has been tested: it is what
+// gets pushed on the stack, so a popped entry never has to go back to the node it came from.  Within a tree the nodes are laid
+// out breadth-first with the two children of a branch adjacent: a branch is expanded with one contiguous 64-byte read.
 struct alignas(16) DNode
 {
     float mn[3];
-    uint32_t a;
+    uint32_t link;
     float mx[3];
-    uint32_t b;
+    uint32_t aux;   // branch: right child (= left + 1); leaf: triangle count; instance: unused
 };
 static_assert(sizeof(DNode) == 32, "node is two 16-byte words");
 

@@ -10,7 +10,7 @@ kw = {"level": int(sys.argv[3])} if len(sys.argv) > 3 else {}
 W, H = 1920, 1080
 t0 = time.time(); sc = getattr(scenes, name)(W, H, **kw); t1 = time.time()
 r = api.Renderer(sc, W, H, max_bounces=8, flags=api.FLAG_TIMING_ALL); t2 = time.time()
-r.render_device(0, 2); r.reset_stats(); r.reset_accumulation()
+r.render_device(0, spp); r.reset_stats(); r.reset_accumulation()  # same batch size as the timed run: no reallocation inside it
 t3 = time.time(); r.render_device(0, spp); r.synchronize(); t4 = time.time()
 st = r.stats()
 print(f"{name} {kw} tris={sc.n_triangles()} gen={t1-t0:.2f}s build={t2-t1:.2f}s render={1e3*(t4-t3):.1f}ms rays={st.rays} -> {st.rays/(t4-t3)/1e6:.0f} Mray/s "

@@ -334,6 +334,33 @@ def test_obj_model_renders_like_its_triangle_soup(api, oracle_mod, tmp_path):
     assert_bit_equal(r.render_samples(0, 3), o.render_samples(48, 32, 3, max_bounces=5), "scene with an OBJ-loaded model")
 
 
+def test_oversized_leaf_bit_exact(api, oracle_mod):
+    """100 coincident triangles end up in ONE leaf (splitting them never pays, blas_bvh.rs:112-122): more than a leaf link can
+    count, so the device BVH refers to it through the big-leaf table.  Hits, leaf order and the image must not care."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Lambertian, Model, SceneDesc
+    tri = np.array([[[-60.0, 40.0, 30.0], [70.0, 45.0, 20.0], [0.0, 150.0, -10.0]]], np.float32)
+    pos = np.repeat(tri, 100, axis=0)
+    nrm = np.repeat(np.array([[[0.0, 0.0, 1.0]] * 3], np.float32), 100, axis=0)
+    sc = SceneDesc.new(scenes.cornell_models() + [Model.new(pos, nrm, Lambertian.new((0.2, 0.3, 0.8)))], scenes.reference_camera(1.0))
+    r = api.Renderer(sc, 32, 32, max_bounces=4); o = oracle_mod.Oracle(sc)
+    d = r.blas_dump(r.blas_count() - 1)
+    assert len(d["kind"]) == 1 and d["kind"][0] == 1 and d["b"][0] == 100        # one leaf holding all hundred
+    rng = np.random.default_rng(11)
+    n = 4000
+    O = np.tile(np.array([0.0, 50.0, 600.0], np.float32), (n, 1)) + rng.normal(size=(n, 3)).astype(np.float32) * 40
+    T = np.stack([rng.uniform(-80, 90, n), rng.uniform(20, 170, n), rng.uniform(-20, 40, n)], 1).astype(np.float32)
+    D = T - O
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    g = r.trace_closest(O, D); c = o.trace_closest(O, D)
+    for k in ("inst", "prim", "t", "u", "v"):
+        assert_bit_equal(g[k], c[k], f"big leaf closest.{k}")
+    assert (g["inst"] == g["inst"].max()).sum() > 500                            # plenty of rays end on the stack of triangles
+    tm = rng.uniform(100, 900, n).astype(np.float32)
+    assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))
+    assert_bit_equal(r.render_samples(0, 2), o.render_samples(32, 32, 2, max_bounces=4), "scene with a 100-triangle leaf")
+
+
 def test_framebuffer_is_visible_to_torch_in_place(api, cornell64):
     """the multi-GPU gather reads libptmi's accumulation buffer through __cuda_array_interface__ (no host round trip)"""
     import torch

@@ -293,7 +293,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     if ((r = take((bytes), (void**)&(ptr)))) return r;
     TAKE(w.st.rec, n_paths * sizeof(DPathRec));
     TAKE(w.st.radiance, n_paths * 16);
-    TAKE(w.st.occl, n_paths * 2);
+    TAKE(w.st.occl, n_paths);
     if (c->sv.has_volumes) { TAKE(w.st.vstack, n_paths * 4); }
     else w.st.vstack = nullptr;
     TAKE(w.st.first_pos, n_paths * 16);

@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 {
                     if (pending)
                     {
-                        out.occl[2u * (size_t)pid + 1u] = (uint8_t)chain_code;
+                        out.occl[pid] = (uint8_t)chain_code;
                         if (chain_code == 0u) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
                     }
                 }
@@ -732,9 +732,17 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     LaneRay w{}, ob{};
     float t_max = 0.0f;
     uint32_t sp = stk.empty(), blas_base = 0;
-    // ANY_SHADOW: `occluded` is PathState::occl (byte pairs by path id, this is byte 0); ANY_HOOK: one word per ray
+    // ANY_SHADOW: `occluded` is PathState::rec: a blocked shadow ray erases the path's explicit-light candidate (integrator.rs:55-56,73)
+    // and a visible one leaves it alone, so the next shading pass needs no separate visibility word; ANY_HOOK: one word per ray
     auto put_result = [&](uint32_t v) {
-        if (MODE == ANY_SHADOW) reinterpret_cast<uint8_t*>(occluded)[2u * (size_t)out_idx] = (uint8_t)v;
+        if (MODE == ANY_SHADOW)
+        {
+            if (v != 0u)
+            {
+                float* e = reinterpret_cast<float*>(&reinterpret_cast<DPathRec*>(occluded)[out_idx].nee_e);
+                e[0] = 0.0f; e[1] = 0.0f; e[2] = 0.0f;
+            }
+        }
         else occluded[out_idx] = v;
     };
     bool in_blas = false;
@@ -949,12 +957,11 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
     const f4 e4 = rec.nee_e;
     const f4 pw4 = rec.nee_pw;
     f3 e = xyz(e4);
-    const uchar2 oc = *reinterpret_cast<const uchar2*>(io.st.occl + 2u * (size_t)pid);
-    if (oc.x != 0u) e = f3{0.0f, 0.0f, 0.0f};               // integrator.rs:55-56,73
+    // (a blocked explicit shadow ray has already zeroed nee_e in the record: k_any<SHADOW>)
     f3 s{0.0f, 0.0f, 0.0f};
     if (flags & FLAG_BSDF_CAST)
     {
-        if (oc.y == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
+        if (io.st.occl[pid] == 0u && pw4.w > 0.0f)                       // integrator.rs:100,103,108 (0 = light hit and visible)
         {
             const uint32_t slot = asu(e4.w); // of the BSDF-sampled ray in last bounce's rq_lchain
             const f4 lh = io.lchain_hit[slot];
@@ -1489,7 +1496,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.occl), &row->valid_shadow);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {

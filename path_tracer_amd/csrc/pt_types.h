@@ -189,9 +189,9 @@ static_assert(sizeof(DPathRec) == 64, "path state layout");
 struct PathState
 {
     DPathRec* rec;
-    // results of the two NEE traversals of the path's last bounce, written by the traversal kernels: dense 2-byte pairs so that
-    // neighbouring paths' results merge into whole sectors.  [2*pid] = explicit shadow ray blocked (0/1); [2*pid+1] = BSDF-sampled
-    // ray: 0 reached a light, 1 blocked before it, 2 no light on the ray
+    // BSDF-sampled NEE ray of the path's last bounce (the few that pass the lights' root box): 0 reached a light, 1 blocked before
+    // it, 2 no light on the ray.  Dense bytes, written by k_closest<LIGHTS>.  (The explicit shadow ray's result needs no word: a
+    // blocked ray zeroes DPathRec::nee_e.)
     uint8_t* occl;
     uint32_t* vstack;   // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
     f4* radiance;       // finished paths: accumulated.xyz (what integrate() returns before the finite check), dense by path id

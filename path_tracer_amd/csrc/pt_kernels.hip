@@ -5,7 +5,8 @@
 //                   persistent-threads ordered traversal; BVH staged in LDS; per-lane stack in LDS;
 //                   ballot/mbcnt refill of idle lanes from the ray queue; material binning of the hits
 //   k_any           tlas.rs:111-144 + blas.rs:257-294   (shadow rays)
-//   k_shade<class>  integrator.rs:163-270 split per material class; NEE of the previous bounce is resolved first
+//   k_shade_surface<class>, k_shade_terminal   integrator.rs:163-270 split per material class; the NEE of the previous bounce is
+//                   resolved first; BSDF-sampled NEE rays that miss the lights' root box are answered on the spot
 //   k_accumulate    integrator.rs:272-280 + accumulate.wgsl:20-23 in sample order
 //
 // Arithmetic: pt_math.h / pt_materials.h.  Built with -ffp-contract=off; v_min/v_max are used in the slab test only

@@ -317,6 +317,9 @@ struct ClosestOut
     uint32_t* first_id;
     uint32_t keep_id_from, keep_pos_from; // path ids at or above these still need first_id / first_pos (last samples of the batch)
     uint32_t finalize_miss;               // 0 when an environment map is set: misses then go to the terminal queue like any bounce
+    // CLOSEST_WORLD: paths that end at this hit or miss are finished here
+    const DPathRec* rec;
+    uint32_t enable_nee;
 };
 
 // Per-lane traversal stack of (node, t_enter) entries.  The position `sp` is opaque to the traversal loop:
@@ -475,6 +478,46 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         }
                         qm = __ballot(pending && !missed);
                         pending = pending && !missed;
+                    }
+                    if (MODE == CLOSEST_WORLD)
+                    {
+                        // A path that ends here — the ray left the scene (integrator.rs:263-266, no environment map) or found a light
+                        // (:207-214) — is finished in this kernel, whose memory pipes are idle, instead of a terminal-queue round trip:
+                        // add what the last bounce still owes (explicit-light estimate; a blocked shadow ray has zeroed it), then the
+                        // ambient term or the emission.  The rare path that also cast a BSDF-sampled NEE ray goes to the queue as before.
+                        bool ends = false, emissive = false;
+                        uint32_t mat_id = 0;
+                        if (pending)
+                        {
+                            if (bid == MISS_ID) ends = out.finalize_miss != 0u;
+                            else
+                            {
+                                const uint4 meta = bl.inst[7u * (bid >> prim_bits) + 6u];
+                                emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
+                                mat_id = meta.z;
+                            }
+                        }
+                        if (ends)
+                        {
+                            const DPathRec& rec = out.rec[pid];
+                            const f4 acc4 = rec.acc;
+                            const uint32_t flags = asu(acc4.w);
+                            if (!(flags & FLAG_BSDF_CAST))
+                            {
+                                f3 acc = xyz(acc4);
+                                if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
+                                const f3 pw = xyz(rec.pw);
+                                if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
+                                else if (!out.enable_nee || (flags & FLAG_LAST_DELTA))
+                                {
+                                    const DMaterial& m = sv.materials[mat_id];
+                                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
+                                }
+                                out.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f};
+                                pending = false;
+                            }
+                        }
+                        qm = __ballot(pending);
                     }
                     if (pending)
                     {
@@ -1492,7 +1535,13 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, &row->head_closest, out);
     }
     else
+    {
+        out.rec = wb.st.rec;
+        out.radiance = wb.st.radiance;
+        out.enable_nee = rp.enable_nee;
+        out.finalize_miss = env.w == 0u ? 1u : 0u;
         launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, &row->head_closest, out);
+    }
 }
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {

@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, ui
 // queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
 // when the producer exits is filled with HOLE markers that consumers skip; the queue's counter therefore counts slots, not
 // entries.  Region size = slots_in / (producers * 16), clamped to [256, 8192]: holes stay below ~6 % of a large queue.
-enum : uint32_t { HOLE = 0xffffffffu };
+enum : uint32_t { HOLE = 0xffffffffu, PATH_ENDS = 0x80000000u /* shadow-ray path ids: see k_any */ };
 struct Region { uint32_t cur, end; };
 __device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers)
 {
@@ -763,7 +763,7 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
-                                              uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid)
+                                              uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid, f4* __restrict__ radiance)
 {
     extern __shared__ uint4 smem[];
     uint32_t blob_words;
@@ -778,12 +778,22 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     uint32_t sp = stk.empty(), blas_base = 0;
     // ANY_SHADOW: `occluded` is PathState::rec: a blocked shadow ray erases the path's explicit-light candidate (integrator.rs:55-56,73)
     // and a visible one leaves it alone, so the next shading pass needs no separate visibility word; ANY_HOOK: one word per ray
+    // A shadow ray whose path id carries PATH_ENDS belongs to a path that died in the shading pass with nothing else owed: its
+    // radiance is completed here (accumulated += path_weight * (explicit + 0), integrator.rs:231-234) instead of in a terminal pass.
+    bool path_ends = false;
     auto put_result = [&](uint32_t v) {
         if (MODE == ANY_SHADOW)
         {
-            if (v != 0u)
+            DPathRec* rec = reinterpret_cast<DPathRec*>(occluded) + out_idx;
+            if (path_ends)
             {
-                float* e = reinterpret_cast<float*>(&reinterpret_cast<DPathRec*>(occluded)[out_idx].nee_e);
+                const f3 e = v != 0u ? f3{0.0f, 0.0f, 0.0f} : xyz(rec->nee_e);
+                const f3 acc = xyz(rec->acc) + xyz(rec->nee_pw) * (e + f3{0.0f, 0.0f, 0.0f});
+                radiance[out_idx] = f4{acc.x, acc.y, acc.z, 0.0f};
+            }
+            else if (v != 0u)
+            {
+                float* e = reinterpret_cast<float*>(&rec->nee_e);
                 e[0] = 0.0f; e[1] = 0.0f; e[2] = 0.0f;
             }
         }
@@ -809,10 +819,11 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
             {
                 const uint32_t mine = first + rank;
                 const f4 a = ra[mine], b = rb[mine];
-                const uint32_t pid = asu(b.w);
-                if (pid != HOLE) {
+                const uint32_t tag = asu(b.w);
+                if (tag != HOLE) {
                 valid_rays += 1u;
-                out_idx = (MODE == ANY_HOOK) ? mine : pid;
+                path_ends = MODE == ANY_SHADOW && (tag & PATH_ENDS) != 0u;
+                out_idx = (MODE == ANY_HOOK) ? mine : (tag & ~PATH_ENDS);
                 w.o = xyz(a);
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
@@ -1110,7 +1121,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint2 e2 = make_uint2(HOLE, 0u);
         if (valid) e2 = io.entries[idx];
         valid = valid && e2.x != HOLE;
-        bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false;
+        bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
         uint32_t pid = 0, flags = 0;
         f3 acc{}, pw{};
@@ -1343,7 +1354,13 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
                 nx_a = f4{next_o.x, next_o.y, next_o.z, asf(0x7f800000u)};
                 nx_b = f4{ndir.x, ndir.y, ndir.z, asf(pid)};
             }
-            else { want_dead = (flags & FLAG_NEE_PENDING) != 0u; }
+            else if (flags & FLAG_NEE_PENDING)
+            {
+                // the path is over but still owes this bounce's direct light (integrator.rs:231-234)
+                if (flags & FLAG_BSDF_CAST) want_dead = true;            // both estimates pending: the terminal pass adds them
+                else if (want_shadow) { ends_with_shadow = true; sh_b.w = asf(pid | PATH_ENDS); } // the shadow-ray kernel finishes it
+                else acc = acc + xyz(nee_pw) * (xyz(nee_e) + f3{0.0f, 0.0f, 0.0f});  // nothing was cast: explicit = bsdf = 0
+            }
         }
         // ---- block-aggregated queue appends (every thread of the block reaches this): one atomic per queue per block
         uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
@@ -1356,7 +1373,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
         if (valid)
         {
-            if (!want_next && !want_dead) io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // the path ended here, nothing owed
+            if (!want_next && !want_dead && !ends_with_shadow) io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // the path ended here, nothing owed
             else
             {
                 DPathRec& rec = io.st.rec[pid];
@@ -1500,16 +1517,16 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
-                            uint32_t* occluded, uint32_t* n_valid)
+                            uint32_t* occluded, uint32_t* n_valid, f4* radiance = nullptr)
 {
     const size_t lds = trace_lds_bytes(tl, false);
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
     const dim3 grid(tl.grid_blocks), block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
-    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_any<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
-    else if (tl.lds_scene) hipLaunchKernelGGL((k_any<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
-    else if (!spill) hipLaunchKernelGGL((k_any<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
-    else hipLaunchKernelGGL((k_any<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid);
+    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_any<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
+    else if (tl.lds_scene) hipLaunchKernelGGL((k_any<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
+    else if (!spill) hipLaunchKernelGGL((k_any<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
+    else hipLaunchKernelGGL((k_any<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
 }
 
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
@@ -1546,7 +1563,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow, wb.st.radiance);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {

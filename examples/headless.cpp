@@ -1,0 +1,93 @@
+// Headless driver: src/main.rs's run() without the window — scene set-up (:75-137), then the event loop's MainEventsCleared
+// body (:179-216) for a number of frames, optionally with scripted camera input, and ImageHelper::write_image at the end.
+// Everything goes through include/ptmi.hpp, i.e. the C-ABI of libptmi.
+//
+//   examples/headless [--width W] [--height H] [--frames N] [--bounces B] [--move] [--models DIR] [--out file.png]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "ptmi.hpp"
+
+using namespace ptmi;
+
+int main(int argc, char** argv)
+{
+    uint32_t width = 1920, height = 1080, frames = 64, bounces = 8; // IMAGE_WIDTH/HEIGHT main.rs:44-45; the reference's MAX_BOUNCES is 1024
+    bool move = false;
+    std::string models_dir = "models/cornell", out = "";
+    for (int i = 1; i < argc; ++i)
+    {
+        const std::string a = argv[i];
+        auto next = [&](const char* what) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--width") width = (uint32_t)std::atoi(next("--width"));
+        else if (a == "--height") height = (uint32_t)std::atoi(next("--height"));
+        else if (a == "--frames") frames = (uint32_t)std::atoi(next("--frames"));
+        else if (a == "--bounces") bounces = (uint32_t)std::atoi(next("--bounces"));
+        else if (a == "--models") models_dir = next("--models");
+        else if (a == "--out") out = next("--out");
+        else if (a == "--move") move = true;
+        else if (a == "--help" || a == "-h")
+        {
+            std::printf("usage: %s [--width W] [--height H] [--frames N] [--bounces B] [--move] [--models DIR] [--out file.png]\n", argv[0]);
+            return 0;
+        }
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    try
+    {
+        // Materials  main.rs:77-92
+        const Material diffuse_gray = Lambertian::New({0.73f, 0.73f, 0.73f});
+        const Material diffuse_green = Lambertian::New({0.12f, 0.45f, 0.15f});
+        const Material diffuse_red = Lambertian::New({0.65f, 0.05f, 0.05f});
+        const Material light = Emissive::New(Vec3A::splat(15.0f));
+
+        // Models and BVHs  main.rs:94-117 (the two blocks the reference has commented out stand in for its dragon, whose file it does not ship)
+        const std::vector<Affine3A> one{Affine3A::IDENTITY()};
+        const Scene scene = Scene::New({
+            Model::New(models_dir + "/cb_light.obj", light, one),
+            Model::New(models_dir + "/cb_main.obj", diffuse_gray, one),
+            Model::New(models_dir + "/cb_right.obj", diffuse_red, one),
+            Model::New(models_dir + "/cb_left.obj", diffuse_green, one),
+            Model::New(models_dir + "/cb_box_tall.obj", diffuse_gray, one),
+            Model::New(models_dir + "/cb_box_short.obj", diffuse_gray, one),
+        });
+
+        // Camera  main.rs:119-128
+        const Vec3A look_from{0.0f, 50.0f, 1000.0f}, look_at{0.0f, 50.0f, 0.0f};
+        const Camera cam = Camera::New(look_from, look_at, 60.0f, (float)width / (float)height, 0.0f, 950.0f);
+        Renderer renderer(scene, cam, width, height, bounces);
+        Mat4 last_inv_proj = renderer.inv_projection();
+
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t frame = 0; frame < frames; ++frame)
+        {
+            if (move && frame >= frames / 2)
+            {
+                // what Camera::input would receive from winit: a key held down and a slow mouse drag, dt = 1/60 s scaled to the
+                // reference's sensitivities (camera.rs:35,43)
+                renderer.input(PT_EV_KEY_W, 0.0f, 0.0f, 2.0e-6f);
+                renderer.input(PT_EV_MOUSE_MOTION, 1.0f, 0.25f, 1.0e-6f);
+            }
+            renderer.frame(frame, last_inv_proj);            // the pixel loop + state.update   main.rs:181-215
+            last_inv_proj = renderer.inv_projection();       // main.rs:216
+        }
+        const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const pt_stats st = renderer.stats();
+        const double rays = (double)st.rays_closest + (double)st.rays_any + (double)st.rays_light_closest;
+        std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"ms_per_frame\": %.3f, \"Mray_per_s\": %.1f}\n", frames, width, height,
+                    1e3 * seconds / (frames ? frames : 1), rays / seconds / 1e6);
+        if (!out.empty()) renderer.write_image(out);         // ImageHelper::write_image
+    }
+    catch (const Error& e)
+    {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

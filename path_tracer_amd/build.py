@@ -25,3 +25,17 @@ def build(force: bool = False) -> str:
             raise RuntimeError("hipcc not found: libptmi.so cannot be built (and there is no fallback path)")
         subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True)
     return LIB_PATH
+
+
+ROOT = os.path.dirname(_HERE)
+HEADLESS = os.path.join(ROOT, "examples", "headless")
+
+
+def build_host_driver(force: bool = False) -> str:
+    """examples/headless: the C++ host side (include/ptmi.hpp) driving the C-ABI the way src/main.rs drives its integrator."""
+    src = os.path.join(ROOT, "examples", "headless.cpp")
+    deps = [src, os.path.join(ROOT, "include", "ptmi.hpp"), os.path.join(ROOT, "include", "pt_api.h"), LIB_PATH]
+    if force or not os.path.exists(HEADLESS) or any(os.path.getmtime(d) > os.path.getmtime(HEADLESS) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), "-o", HEADLESS, src,
+                        "-L" + _HERE, "-lptmi", "-Wl,-rpath,$ORIGIN/../path_tracer_amd"], check=True)
+    return HEADLESS

@@ -194,6 +194,38 @@ def test_write_image_round_trips_through_a_png_decoder(api, oracle_mod, cornell6
     assert e.value.code == -6
 
 
+def test_cpp_host_driver_renders_what_the_oracle_renders(api, oracle_mod, tmp_path):
+    """examples/headless (C++, include/ptmi.hpp) runs main.rs's loop over the OBJ Cornell with a scripted camera; the PNG it writes must
+    hold the bytes the oracle computes for the same frames and events"""
+    import subprocess
+    from conftest import ROOT
+    from path_tracer_amd import build as B, scenes
+    from path_tracer_amd.scene_desc import Model, SceneDesc
+    import os
+    W, H, FRAMES, BOUNCES = 96, 64, 8, 4
+    exe = B.build_host_driver()
+    out_png = tmp_path / "headless.png"
+    run = subprocess.run([exe, "--width", str(W), "--height", str(H), "--frames", str(FRAMES), "--bounces", str(BOUNCES), "--move", "--out", str(out_png)],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert run.returncode == 0, run.stderr
+    assert '"frames": 8' in run.stdout
+    # the same loop on the oracle
+    src = scenes.cornell_models()
+    sc = SceneDesc.new([Model.from_obj(os.path.join(ROOT, "models", "cornell", m.name + ".obj"), m.material) for m in src], scenes.reference_camera(W / H))
+    o = oracle_mod.Oracle(sc)
+    acc = np.zeros((H, W, 4), np.float32); ident = np.zeros((H, W), np.uint32)
+    last = o.inv_projection()
+    for k in range(FRAMES):
+        if k >= FRAMES // 2:
+            o.camera_input(api.EV_KEY_W, 0.0, 0.0, 2.0e-6)
+            o.camera_input(api.EV_MOUSE_MOTION, 1.0, 0.25, 1.0e-6)
+        data, pos, ident, _ = o.render(W, H, 1, first_sample=k, max_bounces=BOUNCES, ident=ident)
+        cur = o.inv_projection()
+        acc = oracle_mod.post_accumulate(data, acc) if np.array_equal(cur, last) else oracle_mod.post_reproject(data, acc, oracle_mod.post_velocity(pos, last), ident)
+        last = cur
+    assert np.array_equal(_read_png(out_png), oracle_mod.post_rgb8(acc))
+
+
 def test_frame_needs_the_whole_image_on_one_rank(api, cornell64):
     r = api.Renderer(cornell64, 64, 64, rank=0, world_size=2)
     with pytest.raises(api.PtError) as e:

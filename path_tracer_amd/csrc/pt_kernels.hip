@@ -87,6 +87,7 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, ui
 // queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
 // when the producer exits is filled with HOLE markers that consumers skip; the queue's counter therefore counts slots, not
 // entries.  Region size = slots_in / (producers * 16), clamped to [256, 8192]: holes stay below ~6 % of a large queue.
+enum : uint32_t { PRIMARY_MISS = 0xffu /* PathState::occl: the camera ray left the scene at once (radiance = ambient) */ };
 enum : uint32_t { HOLE = 0xffffffffu, PATH_ENDS = 0x80000000u /* shadow-ray path ids: see k_any */ };
 struct Region { uint32_t cur, end; };
 __device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers)
@@ -456,9 +457,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                     {
                         // a primary miss is a finished path: accumulated = 0 + 0.006 * 1 (integrator.rs:265), defaults of :156-157
                         const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
+                        // one byte per camera ray instead of a 16-byte radiance record for the (usually many) rays that leave at once:
+                        // k_accumulate reads PRIMARY_MISS as radiance (0.006, 0.006, 0.006)
+                        if (pending) out.occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
                         if (missed)
                         {
-                            out.radiance[ray_idx] = f4{0.006f, 0.006f, 0.006f, 0.0f};
                             if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
                             if (ray_idx >= out.keep_pos_from)
                             {
@@ -1418,7 +1421,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
     for (uint32_t s = 0; s < rp.batch_samples; ++s)
     {
         const uint32_t pid = s * rp.local_pixels + lp;
-        const f3 c = finalise(xyz(st.radiance[pid]));
+        const f3 c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
         a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
         // (id << 16) | new once per sample: only the last two samples survive in 32 bits
         if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
@@ -1432,7 +1435,7 @@ __global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, co
 {
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= rp.n_paths) return;
-    const f3 c = finalise(xyz(st.radiance[pid]));
+    const f3 c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
     out[pid] = f4{c.x, c.y, c.z, 1.0f};
 }
 
@@ -1544,6 +1547,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     {
         out.eye = f3{cam.eye[0], cam.eye[1], cam.eye[2]};
         out.radiance = wb.st.radiance;
+        out.occl = wb.st.occl;
         out.first_pos = wb.st.first_pos;
         out.first_id = wb.st.first_id;
         out.keep_id_from = rp.keep_id_from;

@@ -190,7 +190,9 @@ struct PathState
 {
     DPathRec* rec;
     // BSDF-sampled NEE ray of the path's last bounce (the few that pass the lights' root box): 0 reached a light, 1 blocked before
-    // it, 2 no light on the ray.  Dense bytes, written by k_closest<LIGHTS>.  (The explicit shadow ray's result needs no word: a
+    // it, 2 no light on the ray; written by k_closest<LIGHTS>.  At bounce 0 the byte says whether the camera ray left the scene at
+    // once (0xff: the path's radiance is the ambient term and no radiance record is written) — k_closest<PRIMARY> writes it for
+    // every path of the batch.  Dense bytes.  (The explicit shadow ray's result needs no word: a
     // blocked ray zeroes DPathRec::nee_e.)
     uint8_t* occl;
     uint32_t* vstack;   // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes

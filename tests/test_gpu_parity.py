@@ -250,11 +250,39 @@ def test_large_frame_properties(api):
     assert_bit_equal(a, b, "re-render")
 
 
+def test_full_size_frame_bit_exact_vs_oracle(api, oracle_mod):
+    """BASELINE.json configs[1] geometry at its full 1920x1080 and depth 8, a few samples per pixel: every word of the accumulated frame,
+    first-hit position and id history against the oracle (multi-threaded; a second or so of host time on the GPU box), and the
+    ray tallies of the reference's call sites"""
+    import hashlib
+    from path_tracer_amd import scenes
+    W, H, SPP = 1920, 1080, 3
+    sc = scenes.cornell_box(W, H)
+    r = api.Renderer(sc, W, H, max_bounces=8)
+    o = oracle_mod.Oracle(sc)
+    acc, pos, idb = r.render(0, SPP)
+    oacc, opos, oid, octr = o.render(W, H, SPP, max_bounces=8)
+    assert_bit_equal(acc, oacc, "1080p accumulation"); assert_bit_equal(pos, opos, "1080p position"); assert np.array_equal(idb, oid)
+    st = r.stats()
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+    # sharded the way bench.py --gpus 8 shards it: the strips of all ranks reassemble to the same frame (checksum of checksums)
+    from path_tracer_amd.dist import rows_of_rank
+    whole = hashlib.sha256(acc.tobytes()).hexdigest()
+    again = np.zeros_like(acc)
+    for rank in range(8):
+        rr = api.Renderer(sc, W, H, max_bounces=8, rank=rank, world_size=8, strip_rows=4)
+        part, _, _ = rr.render(0, SPP)
+        again[rows_of_rank(H, rank, 8, 4)] = part
+        rr.close()
+    assert hashlib.sha256(again.tobytes()).hexdigest() == whole
+
+
 @pytest.mark.parametrize("name,kw,flags", [
     ("cornell_box", {}, 2),                      # PT_FLAG_NO_LDS_SCENE: same scene, BVH read from global memory
     ("cornell_spheres", dict(level=3), 0),       # 4.5 k triangles, five material kinds, rotated instance
     ("cornell_mesh", dict(level=4), 0),          # 5 k triangles
     ("cornell_mesh", dict(level=6), 0),          # 82 k triangles (configs[2] class): deep BLAS, BVH in HBM/L2
+    ("cornell_mesh", dict(level=7), 0),          # 328 k triangles (configs[3] class): traversal stack spills past its LDS levels
 ])
 def test_larger_scenes_bit_exact(api, oracle_mod, name, kw, flags):
     from path_tracer_amd import scenes

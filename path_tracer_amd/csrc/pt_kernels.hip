@@ -219,6 +219,26 @@ __device__ __forceinline__ bool tri_planes(const uint4 p0, const uint4 p1, const
     return !(out_t | out_u | out_v);
 }
 
+// the same test in two parts, for leaves that evaluate two triangles side by side: everything that does not depend on t_max ...
+struct TriEval { float td, ud, vd, det; bool uv_ok; };
+__device__ __forceinline__ TriEval tri_eval(const uint4* tp, const f3 mo, const f3 d)
+{
+    TriEval e;
+    const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+    const f4 n0{asf(p0.x), asf(p0.y), asf(p0.z), asf(p0.w)};
+    e.det = dot3(d, xyz(n0));
+    e.td = -dot4(f4{mo.x, mo.y, mo.z, -1.0f}, n0);
+    const f3 p = e.det * mo + e.td * d;
+    const f4 p4{p.x, p.y, p.z, e.det};
+    e.ud = dot4(p4, f4{asf(p1.x), asf(p1.y), asf(p1.z), asf(p1.w)});
+    e.vd = dot4(p4, f4{asf(p2.x), asf(p2.y), asf(p2.z), asf(p2.w)});
+    const bool out_u = sign_differs(e.ud, e.det - e.ud), out_v = sign_differs(e.vd, e.det - e.ud - e.vd);
+    e.uv_ok = !out_u && !out_v;
+    return e;
+}
+// ... and the range test against the current t_max (primitive.rs:122-123)
+__device__ __forceinline__ bool tri_in_range(const TriEval& e, float t_min, float t_mx) { return !sign_differs(e.td - e.det * t_min, e.det * t_mx - e.td); }
+
 struct Blob
 {
     const uint4* nodes; // 2 words per node
@@ -715,22 +735,32 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             {
                 uint32_t first, count;
                 leaf_range(bl, kind, payload, first, count);
-                for (uint32_t k = 0; k < count; ++k)         // blas.rs:230-251
-                {
-                    const uint4* tp = bl.tris + 3u * (first + k);
-                    float td, ud, vd, det;
-                    if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_est, td, ud, vd, det))
+                // blas.rs:230-251, two triangles at a time (a quad is the commonest leaf): both are evaluated side by side, then
+                // accepted in leaf order, the second against the t_max the first may have lowered
+                const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
+                const float t_min = PT_EPSILON - t_est;
+                auto accept = [&](const TriEval& e, uint32_t tri) {
+                    if (e.uv_ok && tri_in_range(e, t_min, t_max - t_est))
                     {
                         // primitive.rs:158-170: (t,u,v) = xyz / det ; t += t_estimate
-                        bt = td / det + t_est;
-                        hud = ud;
-                        hvd = vd;
-                        hdet = det;
-                        t_max = bt;
-                        bid = (inst << prim_bits) | (first + k);
-                        if (bt != bt) { sp = stk.empty(); in_blas = false; break; } // NaN t_max: nothing else can be accepted
+                        bt = e.td / e.det + t_est;
+                        hud = e.ud;
+                        hvd = e.vd;
+                        hdet = e.det;
+                        t_max = bt;                          // a NaN here rejects everything that follows (tri_in_range is unordered)
+                        bid = (inst << prim_bits) | tri;
                     }
+                };
+                uint32_t k = 0;
+                for (; k + 1u < count; k += 2u)
+                {
+                    const uint4* tp = bl.tris + 3u * (first + k);
+                    const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
+                    accept(ea, first + k);
+                    accept(eb, first + k + 1u);
                 }
+                if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
+                if (bt != bt) { sp = stk.empty(); in_blas = false; } // NaN t_max: nothing else can be accepted anywhere
             }
         }
     }

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3];
                 t_est = 0.0f;
             }
-            const uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+            uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
             if (kind == NODE_BRANCH)
             {
                 // push_to_stack  blas.rs:133-162; the children are one contiguous 64-byte record pair
@@ -729,9 +729,21 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                 const bool left_near = tl < tr;
                 const uint2 le = make_uint2(l0.w, asu(tl)), re = make_uint2(r0.w, asu(tr));
                 if (hl && hr) { stk.put(sp, left_near ? re : le); sp = stk.up(sp); }
-                if (hl || hr) { stk.put(sp, (hl && (left_near || !hr)) ? le : re); sp = stk.up(sp); }
+                if (hl || hr)
+                {
+                    // the entry the reference pops next.  A triangle leaf is dealt with in this very step (its pop test t_enter > t_max
+                    // cannot fire: the box was just met within t_max); anything else goes on the stack
+                    const uint2 near = (hl && (left_near || !hr)) ? le : re;
+                    if ((near.x >> NODE_KIND_SHIFT) & 1u) // NODE_TRIS or NODE_TRIS_BIG
+                    {
+                        kind = near.x >> NODE_KIND_SHIFT;
+                        payload = near.x & NODE_PAYLOAD_MASK;
+                        t_est = asf(near.y);
+                    }
+                    else { stk.put(sp, near); sp = stk.up(sp); }
+                }
             }
-            else
+            if (kind & 1u)
             {
                 uint32_t first, count;
                 leaf_range(bl, kind, payload, first, count);

@@ -1015,6 +1015,13 @@ __global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const C
     // no state is initialised: bounce 0 knows path_weight = 1, accumulated = 0, one draw consumed (integrator.rs:153-161)
 }
 
+// Streaming accesses of the shading pass: rays and hit records are written once and read once, by the next kernel, long after the
+// ~200 GB in between have flushed every cache; "nt" accesses keep them from displacing the records and scene tables in L2
+// (same-box A/B: -0.6 ms per frame; the 64-byte path records must NOT be streamed: their four words merge in L2, +4 ms without).
+typedef float nt4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(f4* p, f4 v) { __builtin_nontemporal_store(nt4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4_t*>(p)); }
+__device__ __forceinline__ f4 nt_load(const f4* p) { const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p)); return f4{v.x, v.y, v.z, v.w}; }
+
 struct ShadeIO
 {
     PathState st;
@@ -1178,8 +1185,8 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         {
             const uint32_t entry = e2.x;
             pid = e2.y; // carried in the queue entry so that the state loads do not wait for the ray record
-            const f4 ra = bounce == 0u ? io.primary_a : io.rq_in.a[entry];
-            const f4 rb = io.rq_in.b[entry], hit = io.hits[entry];
+            const f4 ra = bounce == 0u ? io.primary_a : nt_load(io.rq_in.a + entry);
+            const f4 rb = nt_load(io.rq_in.b + entry), hit = nt_load(io.hits + entry);
             f4 pw4{1.0f, 1.0f, 1.0f, asf(1u)}; // bounce 0: path_weight = 1, accumulated = 0, the seed draw consumed
             acc = f3{0.0f, 0.0f, 0.0f};
             flags = 0u;
@@ -1414,9 +1421,9 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
         uint32_t pos[4];
         block_append4(sh_append, ctrs, preds, rsize, pos);
-        if (want_shadow) { io.rq_shadow.a[pos[0]] = sh_a; io.rq_shadow.b[pos[0]] = sh_b; }
+        if (want_shadow) { nt_store(io.rq_shadow.a + pos[0], sh_a); nt_store(io.rq_shadow.b + pos[0], sh_b); }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
-        if (want_next) { io.rq_out.a[pos[2]] = nx_a; io.rq_out.b[pos[2]] = nx_b; }
+        if (want_next) { nt_store(io.rq_out.a + pos[2], nx_a); nt_store(io.rq_out.b + pos[2], nx_b); }
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
         if (valid)
         {

@@ -43,6 +43,8 @@ struct pt_ctx
     int device = 0;
     int n_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;            // the (tiny) BSDF-sampled NEE launch runs beside the shadow-ray launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // scene residency
     bool scene_uploaded = false;
@@ -146,6 +148,9 @@ int ensure_device(pt_ctx* c)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (!c->stream) c->stream = c->own_stream;
     c->dev_ready = true;
     return PT_OK;
@@ -423,13 +428,30 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * 8);
     const bool nee = g.enable_nee != 0;
+    // The two NEE launches of a bounce are independent (different rays in, different words out).  The BSDF-sampled one has almost
+    // nothing to do since shading answers the rays that miss the lights' root box (it is all launch latency and tail), so it runs on a
+    // side stream beside the shadow-ray launch; the main stream waits for it before the next closest-hit launch.
+    int nee_err = PT_OK;
+    auto nee_launches = [&](uint32_t row) {
+        const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
+        if (timing_all)
+        {
+            { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, row); }
+            { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, row); }
+            return;
+        }
+        if (hipEventRecord(c->ev_fork, s) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
+        launch_trace_lchain(c->side_stream, tl, wb, row);
+        if (hipEventRecord(c->ev_join, c->side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
+        launch_trace_shadow(s, tl, wb, row);
+        if (hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
+    };
     uint32_t last_row = rows - 1;
     for (uint32_t b = 0; b <= g.max_bounces; ++b)
     {
         if (b > 0 && nee)
         {
-            { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, b - 1); }
-            { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, b - 1); }
+            nee_launches(b - 1);
         }
         { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
         for (uint32_t q = 0; q < Q_COUNT; ++q)
@@ -447,10 +469,10 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     // the last shading pass may still owe direct-light estimates: trace them, then a resolve-only terminal pass
     if (nee)
     {
-        { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, last_row - 1); }
-        { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, last_row - 1); }
+        nee_launches(last_row - 1);
         { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
     }
+    if (nee_err) return fail(c, PT_ERR_HIP, "stream fork/join failed");
     if (samples_out)
     {
         launch_store_samples(s, rp, wb, samples_out);
@@ -565,6 +587,9 @@ void pt_destroy(pt_ctx* c)
         if (c->h_counters) (void)hipHostFree(c->h_counters);
         for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     }
     delete c;
 }

@@ -1429,20 +1429,34 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
         if (want_next) { nt_store(io.rq_out.a + pos[2], nx_a); nt_store(io.rq_out.b + pos[2], nx_b); }
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
-        if (valid)
+        const bool write_rec = valid && (want_next || want_dead || ends_with_shadow);
+        if (valid && !write_rec) io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // the path ended here, nothing owed
+        // The 64-byte record is stored by the four lanes of a quad together, one whole record per store instruction (each lane a
+        // 16-byte word): L2 then sees one full-sector write per record instead of four partial ones.  4x4 transposes inside the quad.
         {
-            if (!want_next && !want_dead && !ends_with_shadow) io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // the path ended here, nothing owed
-            else
+            float m[4][4] = {{pw.x, pw.y, pw.z, asf(draws)}, {acc.x, acc.y, acc.z, asf(flags)}, {nee_e.x, nee_e.y, nee_e.z, nee_e.w}, {nee_pw.x, nee_pw.y, nee_pw.z, nee_pw.w}};
+            const uint32_t q = threadIdx.x & 3u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) // component c of the four words: m[word][c]
             {
-                DPathRec& rec = io.st.rec[pid];
-                rec.pw = f4{pw.x, pw.y, pw.z, asf(draws)};
-                rec.acc = f4{acc.x, acc.y, acc.z, asf(flags)};
-                if (flags & FLAG_NEE_PENDING)
-                {
-                    rec.nee_e = nee_e;
-                    rec.nee_pw = nee_pw;
-                }
+                float a0 = m[0][c], a1 = m[1][c], a2 = m[2][c], a3 = m[3][c];
+                // exchange with lane ^ 1
+                { const float t = (q & 1u) ? a0 : a1; const float r = asf(__builtin_amdgcn_mov_dpp(asu(t), 0xB1, 0xF, 0xF, true)); if (q & 1u) a0 = r; else a1 = r; }
+                { const float t = (q & 1u) ? a2 : a3; const float r = asf(__builtin_amdgcn_mov_dpp(asu(t), 0xB1, 0xF, 0xF, true)); if (q & 1u) a2 = r; else a3 = r; }
+                // exchange with lane ^ 2
+                { const float t = (q & 2u) ? a0 : a2; const float r = asf(__builtin_amdgcn_mov_dpp(asu(t), 0x4E, 0xF, 0xF, true)); if (q & 2u) a0 = r; else a2 = r; }
+                { const float t = (q & 2u) ? a1 : a3; const float r = asf(__builtin_amdgcn_mov_dpp(asu(t), 0x4E, 0xF, 0xF, true)); if (q & 2u) a1 = r; else a3 = r; }
+                m[0][c] = a0; m[1][c] = a1; m[2][c] = a2; m[3][c] = a3; // now m[k][c] = component c of word q of quad member k
             }
+            const uint32_t wr = write_rec ? 1u : 0u;
+#define PT_QUAD_STORE(K, SEL)                                                                                                   \
+            {                                                                                                                      \
+                const uint32_t pid_k = __builtin_amdgcn_mov_dpp(pid, SEL, 0xF, 0xF, true); /* quad_perm [K,K,K,K] */               \
+                const uint32_t wr_k = __builtin_amdgcn_mov_dpp(wr, SEL, 0xF, 0xF, true);                                           \
+                if (wr_k != 0u) reinterpret_cast<f4*>(io.st.rec + pid_k)[q] = f4{m[K][0], m[K][1], m[K][2], m[K][3]};             \
+            }
+            PT_QUAD_STORE(0, 0x00) PT_QUAD_STORE(1, 0x55) PT_QUAD_STORE(2, 0xAA) PT_QUAD_STORE(3, 0xFF)
+#undef PT_QUAD_STORE
         }
     }
     {

@@ -25,6 +25,8 @@ def main(src, tag):
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for _, r in ks.iterrows():
         lines.append(f"| {r['kernel']} | {r['Calls']} | {r['TotalDurationNs'] / 1e6:.2f} | {r['AverageNs'] / 1e3:.1f} | {r['Percentage']:.2f} |")
+    lines += ["", "`k_closest<.., 1, ..>` (the BSDF-sampled NEE rays, about 1 % of them since the shading pass culls the rest) is launched on a side stream "
+              "beside `k_any`: its duration overlaps `k_any`'s and mostly measures waiting for wave slots, so the column sums exceed the wall time."]
     traffic = {}
     frames = []
     for d in sorted(os.listdir(src)):

@@ -45,7 +45,7 @@ struct WaveRange
 __device__ __forceinline__ uint32_t fetch_chunk_size(uint32_t n)
 {
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t c = n / (waves * 4u);
+    uint32_t c = n / (waves * 2u); // two chunks per wave when the queue is short (same-box sweep over 1, 2, 3, 4, 8: 2 is best)
     c = c < 64u ? 64u : (c > 2048u ? 2048u : c);
     return (c + 63u) & ~63u;
 }

@@ -20,6 +20,13 @@
 
 using namespace pt;
 
+#ifndef PT_SHADE_BLOCKS_PER_CU
+#define PT_SHADE_BLOCKS_PER_CU 12  // persistent shading workgroups per CU (same-box sweep over 4, 6, 8, 12, 16)
+#endif
+#ifndef PT_TRACE_BLOCKS_PER_CU_MAX
+#define PT_TRACE_BLOCKS_PER_CU_MAX 8
+#endif
+
 namespace {
 
 enum TimeCat { T_GEN = 0, T_WORLD, T_ANY, T_LIGHT, T_SHADE, T_ACCUM, T_COUNT };
@@ -221,7 +228,7 @@ int upload_scene(pt_ctx* c)
     c->block_threads = threads;
     const size_t lds = lds_need(threads);
     uint32_t per_cu = (uint32_t)std::min<size_t>((160 * 1024) / std::max<size_t>(lds, 1), 2048 / threads);
-    per_cu = std::max(1u, std::min(per_cu, 8u));
+    per_cu = std::max(1u, std::min(per_cu, (uint32_t)PT_TRACE_BLOCKS_PER_CU_MAX));
     c->trace_blocks = (uint32_t)c->n_cus * per_cu;
     sv.stack_spill = nullptr;
     if (sv.stack_entries > sv.stack_lds)
@@ -426,7 +433,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
 
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
     { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
-    const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * 8);
+    const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU);
     const bool nee = g.enable_nee != 0;
     // The two NEE launches of a bounce are independent (different rays in, different words out).  The BSDF-sampled one has almost
     // nothing to do since shading answers the rays that miss the lights' root box (it is all launch latency and tail), so it runs on a

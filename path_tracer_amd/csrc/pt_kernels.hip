@@ -3,8 +3,9 @@
 //   k_generate      main.rs:186-199   seed draw, shuffled-scrambled Sobol jitter, camera ray
 //   k_closest       tlas.rs:66-110 + blas.rs:214-256 + boundingbox.rs:115-131 + primitive.rs:117-178
 //                   persistent-threads ordered traversal; BVH staged in LDS; per-lane stack in LDS;
-//                   ballot/mbcnt refill of idle lanes from the ray queue; material binning of the hits
-//   k_any           tlas.rs:111-144 + blas.rs:257-294   (shadow rays)
+//                   ballot/mbcnt refill of idle lanes from the ray queue; material binning of the hits;
+//                   paths that end at the hit or miss are finished here (integrator.rs:207-214, 263-266)
+//   k_any           tlas.rs:111-144 + blas.rs:257-294   (shadow rays; finishes paths that died owing one explicit-light estimate)
 //   k_shade_surface<class>, k_shade_terminal   integrator.rs:163-270 split per material class; the NEE of the previous bounce is
 //                   resolved first; BSDF-sampled NEE rays that miss the lights' root box are answered on the spot
 //   k_accumulate    integrator.rs:272-280 + accumulate.wgsl:20-23 in sample order

@@ -46,7 +46,8 @@ class MaterialDesc(C.Structure):
 class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_bounces", C.c_uint32), ("n_sobol", C.c_uint32),
                 ("enable_nee", C.c_uint32), ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-                ("strip_rows", C.c_uint32), ("batch_spp", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("strip_rows", C.c_uint32), ("batch_spp", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("stack_lds_levels", C.c_uint32), ("queue_slack", C.c_uint32), ("pipelines", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -149,15 +150,24 @@ class Renderer:
 
     def __init__(self, scene: SceneDesc, width: int, height: int, max_bounces: int = 8, n_sobol: int = 512, enable_nee: bool = True,
                  seed: int = DEFAULT_SEED, rank: int = 0, world_size: int = 1, strip_rows: int = 4, batch_spp: int = 0, device: int = -1,
-                 flags: int = 0):
+                 flags: int = 0, stack_lds_levels: int = 0, queue_slack: int = 0, pipelines: int = 0):
         self.L = lib()
-        self.cfg = Config(width, height, max_bounces, n_sobol, int(enable_nee), seed, rank, world_size, strip_rows, batch_spp, device, flags)
+        self.cfg = Config(width, height, max_bounces, n_sobol, int(enable_nee), seed, rank, world_size, strip_rows, batch_spp, device, flags,
+                          stack_lds_levels, queue_slack, pipelines, 0)
         self.ctx = C.c_void_p(self.L.pt_create(C.byref(self.cfg)))
         if not self.ctx:
             raise PtError(-1, "pt_create failed (bad configuration)")
         self.desc = scene
-        mats = scene.materials()
-        for m in mats:
+        self._materials = []
+        for mod in scene.models:
+            self.add_model(mod)
+        self.rebuild()
+        if scene.camera is not None:
+            self.set_camera(scene.camera)
+
+    def _material_index(self, m) -> int:
+        """pt_add_material once per distinct material, in first-use order (SceneDesc.materials() gives the same indices)"""
+        if m not in self._materials:
             d = MaterialDesc()
             d.kind = m.kind
             d.colour[:] = m.colour
@@ -167,16 +177,19 @@ class Renderer:
                 d.vol_absorption[:] = m.volume.absorption
                 d.vol_k, d.vol_c, d.vol_g = m.volume.k, m.volume.c, m.volume.g
             self._chk(self.L.pt_add_material(self.ctx, C.byref(d)), allow_positive=True)
-        for mod in scene.models:
-            if getattr(mod, "obj_path", None):
-                self._chk(self.L.pt_add_model_obj(self.ctx, mod.obj_path.encode(), mats.index(mod.material), _p(mod.matrices),
-                                                  mod.matrices.shape[0]), allow_positive=True)
-            else:
-                self._chk(self.L.pt_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0],
-                                              mats.index(mod.material), _p(mod.matrices), mod.matrices.shape[0]), allow_positive=True)
+            self._materials.append(m)
+        return self._materials.index(m)
+
+    def add_model(self, mod) -> int:
+        """Model::new + push onto the scene's model list; call rebuild() (Scene::new) before the next render"""
+        mi = self._material_index(mod.material)
+        if getattr(mod, "obj_path", None):
+            return self._chk(self.L.pt_add_model_obj(self.ctx, mod.obj_path.encode(), mi, _p(mod.matrices), mod.matrices.shape[0]), allow_positive=True)
+        return self._chk(self.L.pt_add_model(self.ctx, _p(mod.positions), _p(mod.normals), mod.positions.shape[0], mi, _p(mod.matrices),
+                                             mod.matrices.shape[0]), allow_positive=True)
+
+    def rebuild(self):
         self._chk(self.L.pt_build(self.ctx))
-        if scene.camera is not None:
-            self.set_camera(scene.camera)
 
     # ---- plumbing
     def _chk(self, r, allow_positive=False):

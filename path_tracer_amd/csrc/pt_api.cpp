@@ -56,6 +56,7 @@ struct pt_ctx
     // scene residency
     bool scene_uploaded = false;
     DevBuf d_spill;
+    size_t spill_region_words = 0; // 8-byte words per traversal launch's spill area (d_spill holds two)
     DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights, d_env;
     std::vector<f4> h_env;
     uint32_t env_w = 0, env_h = 0;
@@ -221,7 +222,7 @@ int upload_scene(pt_ctx* c)
 #ifndef PT_STACK_LDS_LEVELS
 #define PT_STACK_LDS_LEVELS 14
 #endif
-    sv.stack_lds = std::min<uint32_t>(sv.stack_entries, PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
+    sv.stack_lds = std::min<uint32_t>(sv.stack_entries, c->cfg.stack_lds_levels ? c->cfg.stack_lds_levels : PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
     auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
@@ -233,8 +234,11 @@ int upload_scene(pt_ctx* c)
     sv.stack_spill = nullptr;
     if (sv.stack_entries > sv.stack_lds)
     {
+        // two regions: the BSDF-sampled NEE launch runs on the side stream BESIDE the shadow-ray launch (nee_launches), and the spill
+        // slots are indexed by lane only, so concurrent traversal kernels must not share them
         const size_t lanes = (size_t)c->trace_blocks * threads;
-        if ((r = dev_alloc(c, c->d_spill, (size_t)(sv.stack_entries - sv.stack_lds) * lanes * 8))) return r;
+        c->spill_region_words = (size_t)(sv.stack_entries - sv.stack_lds) * lanes;
+        if ((r = dev_alloc(c, c->d_spill, 2 * c->spill_region_words * 8))) return r;
         sv.stack_spill = (uint64_t*)c->d_spill.p;
     }
 
@@ -247,10 +251,11 @@ int upload_scene(pt_ctx* c)
     return PT_OK;
 }
 
-TraceLaunch trace_launch(pt_ctx* c)
+TraceLaunch trace_launch(pt_ctx* c, bool side_stream = false)
 {
     TraceLaunch tl;
     tl.scene = c->sv;
+    if (side_stream && tl.scene.stack_spill) tl.scene.stack_spill += c->spill_region_words;
     tl.blob = c->d_blob.p;
     tl.lds_scene = c->lds_scene;
     tl.grid_blocks = c->trace_blocks;
@@ -278,7 +283,9 @@ int ensure_frame(pt_ctx* c)
 int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
 {
     const bool vstack_ok = !c->sv.has_volumes || c->wb.st.vstack != nullptr;
-    if (c->cap_paths >= n_paths && c->cap_rows >= rows && vstack_ok) return PT_OK;
+    bool queues_ok = true; // a scene edit may have introduced a material class the pool has no shade queue for
+    for (uint32_t q = 1; q < Q_COUNT; ++q) queues_ok = queues_ok && (!c->class_present[q] || c->wb.q_shade[q] != nullptr);
+    if (c->cap_paths >= n_paths && c->cap_rows >= rows && vstack_ok && queues_ok) return PT_OK;
     for (DevBuf& b : c->pool) dev_free(b);
     c->pool.clear();
     if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
@@ -410,7 +417,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     const uint32_t rows = g.max_bounces + 2;
     hipStream_t s = c->stream;
     const WavefrontBuffers& wb = c->wb;
-    const TraceLaunch tl = trace_launch(c);
+    const TraceLaunch tl = trace_launch(c), tl_side = trace_launch(c, true);
     CameraView cam{};
     std::memcpy(cam.ray_matrix, c->scene.camera.ray_matrix, 64);
     cam.eye[0] = c->scene.camera.matrix.t.x;
@@ -448,7 +455,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
             return;
         }
         if (hipEventRecord(c->ev_fork, s) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
-        launch_trace_lchain(c->side_stream, tl, wb, row);
+        launch_trace_lchain(c->side_stream, tl_side, wb, row);
         if (hipEventRecord(c->ev_join, c->side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
         launch_trace_shadow(s, tl, wb, row);
         if (hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
@@ -527,7 +534,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     if ((r = upload_scene(c))) return r;
     if ((r = ensure_frame(c))) return r;
     // Auto batch: as many samples per pixel resident as HBM allows (fewer, larger launches: the late bounces of a small batch
-    // cannot fill 256 CUs).  ~390 B of wavefront state per path; ray indices are 29-bit.
+    // cannot fill 256 CUs).  ~390 B of wavefront state per path; path ids are 29-bit (queue slot indices use all 32).
     size_t max_paths = (size_t)96 << 20;
     {
         size_t free_b = 0, total_b = 0;
@@ -541,7 +548,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     }
     uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
     batch = std::min(batch, n_samples);
-    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (ray indices are 29-bit)");
+    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
     const uint32_t n_batches = (n_samples + batch - 1) / batch;
     batch = (n_samples + n_batches - 1) / n_batches;
     if ((r = ensure_wavefront(c, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;

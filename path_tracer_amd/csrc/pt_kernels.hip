@@ -438,9 +438,11 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
         for (uint32_t j = 0; j < 4; ++j)
         {
             const uint32_t k = j * 64u + lane_id();
-            const uint2 e = k < staged ? stage_idx[k] : make_uint2(0xffffffffu, 0u);
-            idx[j] = make_uint2(e.x & 0x1fffffffu, e.y);
-            cls[j] = e.x >> 29;
+            // the class rides in the top bits of the PATH id (path ids are below 2^29, pt_api.cpp; ray indices are queue slots, holes
+            // included, and may use all 32 bits)
+            const uint2 e = k < staged ? stage_idx[k] : make_uint2(0u, 0xffffffffu);
+            idx[j] = make_uint2(e.x, e.y & 0x1fffffffu);
+            cls[j] = e.y >> 29;
         }
 #pragma unroll
         for (uint32_t c = 0; c < Q_COUNT; ++c)
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
                         const uint32_t k = staged + mbcnt64(qm);
                         const uint32_t cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
-                        stage_idx[k] = make_uint2(ray_idx | (cls << 29), pid);
+                        stage_idx[k] = make_uint2(ray_idx, pid | (cls << 29));
                     }
                     staged += (uint32_t)__popcll(qm);
                     if (staged > kStageCap - 64u) flush_stage();

@@ -277,6 +277,90 @@ def test_full_size_frame_bit_exact_vs_oracle(api, oracle_mod):
     assert hashlib.sha256(again.tobytes()).hexdigest() == whole
 
 
+def test_bench_configuration_bit_exact_vs_oracle(api, oracle_mod):
+    """BASELINE.json configs[1] exactly as bench.py times it: 1920x1080, 256 spp, depth 8, the default (auto) wavefront batch —
+    every word of accumulation, first-hit position and id history, and the three ray tallies, against the oracle (about 20 s of
+    host time on the GPU box's cores)."""
+    from path_tracer_amd import scenes
+    W, H, SPP = 1920, 1080, 256
+    sc = scenes.cornell_box(W, H)
+    r = api.Renderer(sc, W, H, max_bounces=8)
+    acc, pos, idb = r.render(0, SPP)
+    st = r.stats()
+    r.close()
+    oacc, opos, oid, octr = oracle_mod.Oracle(sc).render(W, H, SPP, max_bounces=8)
+    assert_bit_equal(acc, oacc, "1080p x 256 spp accumulation"); assert_bit_equal(pos, opos, "position"); assert np.array_equal(idb, oid)
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest, st.paths) == (int(octr[0]), int(octr[1]), int(octr[2]), W * H * SPP)
+
+
+@pytest.mark.parametrize("name,kw", [("cornell_mixed", {}), ("cornell_spheres", dict(level=4))])
+def test_config5_parameters_bit_exact(api, oracle_mod, name, kw):
+    """BASELINE.json configs[4] at its real parameters: 4096x4096, depth 16, a 4096-spp Sobol table (N = 2 * spp = 8192), the LAST two
+    samples [4094, 4096), rendered in two wavefront batches; mixed materials (diffuse + dielectric + GGX metal [+ mirror, instanced])."""
+    from path_tracer_amd import scenes
+    W = H = 4096
+    sc = getattr(scenes, name)(W, H, **kw)
+    r = api.Renderer(sc, W, H, max_bounces=16, n_sobol=8192, batch_spp=1)
+    acc, pos, idb = r.render(4094, 2)
+    st = r.stats()
+    r.close()
+    oacc, opos, oid, octr = oracle_mod.Oracle(sc).render(W, H, 2, first_sample=4094, max_bounces=16, n_sobol=8192)
+    assert_bit_equal(acc, oacc, f"{name} 4096^2 depth 16 accumulation"); assert_bit_equal(pos, opos, "position"); assert np.array_equal(idb, oid)
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+
+
+@pytest.mark.parametrize("level", [6, 7])
+def test_mesh_scenes_full_frame_bit_exact(api, oracle_mod, level):
+    """BASELINE.json configs[2]/[3] class (82 k / 328 k triangles, BVH in HBM / L2) at the full 1920x1080, depth 8, one sample"""
+    from path_tracer_amd import scenes
+    W, H = 1920, 1080
+    sc = scenes.cornell_mesh(W, H, level=level)
+    r = api.Renderer(sc, W, H, max_bounces=8)
+    acc, pos, idb = r.render(0, 1)
+    st = r.stats()
+    r.close()
+    oacc, opos, oid, octr = oracle_mod.Oracle(sc).render(W, H, 1, max_bounces=8)
+    assert_bit_equal(acc, oacc, f"mesh level {level} 1080p accumulation"); assert_bit_equal(pos, opos, "position"); assert np.array_equal(idb, oid)
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+
+
+def test_spilling_stacks_do_not_race_between_concurrent_launches(api, oracle_mod):
+    """With only two stack levels in LDS every deeper level of every traversal lives in global memory; the shadow-ray launch and
+    the BSDF-sampled NEE launch run side by side on two streams and must not share those slots (large lights so that the NEE
+    launch is not empty; enough rays that the two kernels really overlap)."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Emissive, Model, SceneDesc
+    W, H = 640, 360
+    base = scenes.cornell_mesh(W, H, level=5)
+    # a second, huge emitter: the right wall's twin, slightly inside it, so that most BSDF-sampled NEE rays pass the lights' root box
+    wall = scenes.cornell_models()[2]
+    big = Model.new(wall.positions * np.float32(0.98), wall.normals, Emissive.new((2.0, 1.5, 1.0)), None, "big_light")
+    sc = SceneDesc.new(list(base.models) + [big], base.camera, "spill_race")
+    r = api.Renderer(sc, W, H, max_bounces=6, stack_lds_levels=2)
+    g = r.render_samples(0, 2)
+    assert r.stats().stack_entries > 2
+    c = oracle_mod.Oracle(sc).render_samples(W, H, 2, max_bounces=6)
+    assert_bit_equal(g, c, "spill-everything traversal with concurrent NEE launches")
+
+
+def test_scene_edit_adds_a_material_class(api, oracle_mod):
+    """render, add a model of a material class the context has not seen (its shade queue does not exist yet), rebuild, render again"""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import GGX, Model, SceneDesc, Specular
+    base = scenes.cornell_box(64, 48)
+    r = api.Renderer(base, 64, 48, max_bounces=6)
+    r.render(0, 2)
+    t, n = scenes.sphere_mesh(2, (0.0, 120.0, 60.0), 70.0)
+    extra = [Model.new(t.astype(np.float32), n.astype(np.float32), Specular.new((0.9, 0.9, 0.9)), None, "mirror"),
+             Model.new((t + np.float64(1.0)).astype(np.float32) * np.float32(0.5), n.astype(np.float32), GGX.new_metal((0.8, 0.6, 0.2), 0.3), None, "metal")]
+    for m in extra:
+        r.add_model(m)
+    r.rebuild()
+    g = r.render_samples(0, 3)
+    sc2 = SceneDesc.new(list(base.models) + extra, base.camera, "edited")
+    assert_bit_equal(g, oracle_mod.Oracle(sc2).render_samples(64, 48, 3, max_bounces=6), "scene after adding specular + GGX models")
+
+
 @pytest.mark.parametrize("name,kw,flags", [
     ("cornell_box", {}, 2),                      # PT_FLAG_NO_LDS_SCENE: same scene, BVH read from global memory
     ("cornell_spheres", dict(level=3), 0),       # 4.5 k triangles, five material kinds, rotated instance

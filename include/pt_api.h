@@ -69,7 +69,8 @@ typedef struct pt_config
     uint32_t stack_lds_levels; /* traversal-stack levels kept in LDS (default 14); deeper levels of deep BVHs spill to HBM */
     uint32_t queue_slack;      /* extra ray-queue slots beyond one per path, in 1/1024ths of the path count (default 128 = 1/8, plus a
                                   constant); producers reserve queue regions and return unused tails as holes.  A queue that would
-                                  overflow is never written past its end: the render returns PT_ERR_LIMIT.  Tests pass 1 to see that. */
+                                  overflow is never written past its end: the render returns PT_ERR_LIMIT.  Tests set bit 31 to see that:
+                                  the low 16 bits are then the WHOLE capacity in 1/1024ths of the path count. */
     uint32_t pipelines;        /* wavefront batches in flight on separate HIP streams (default 2; 1 = strictly one after another) */
     uint32_t reserved;
 } pt_config;

@@ -23,6 +23,12 @@ using namespace pt;
 #ifndef PT_SHADE_BLOCKS_PER_CU
 #define PT_SHADE_BLOCKS_PER_CU 12  // persistent shading workgroups per CU (same-box sweep over 4, 6, 8, 12, 16)
 #endif
+#ifndef PT_JOIN_LATE
+#define PT_JOIN_LATE 1
+#endif
+#ifndef PT_SIDE_PRIORITY
+#define PT_SIDE_PRIORITY 1
+#endif
 #ifndef PT_TRACE_BLOCKS_PER_CU_MAX
 #define PT_TRACE_BLOCKS_PER_CU_MAX 8
 #endif
@@ -156,7 +162,11 @@ int ensure_device(pt_ctx* c)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0; // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, PT_SIDE_PRIORITY ? hi : lo));
+    }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (!c->stream) c->stream = c->own_stream;
@@ -259,6 +269,7 @@ TraceLaunch trace_launch(pt_ctx* c, bool side_stream = false)
     tl.blob = c->d_blob.p;
     tl.lds_scene = c->lds_scene;
     tl.grid_blocks = c->trace_blocks;
+    tl.n_cus = (uint32_t)c->n_cus;
     tl.block_threads = c->block_threads;
     return tl;
 }
@@ -284,16 +295,25 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
 {
     const bool vstack_ok = !c->sv.has_volumes || c->wb.st.vstack != nullptr;
     bool queues_ok = true; // a scene edit may have introduced a material class the pool has no shade queue for
-    for (uint32_t q = 1; q < Q_COUNT; ++q) queues_ok = queues_ok && (!c->class_present[q] || c->wb.q_shade[q] != nullptr);
+    for (uint32_t q = 1; q < Q_COUNT; ++q) queues_ok = queues_ok && (!c->class_present[q] || ((c->wb.class_mask >> q) & 1u));
     if (c->cap_paths >= n_paths && c->cap_rows >= rows && vstack_ok && queues_ok) return PT_OK;
     for (DevBuf& b : c->pool) dev_free(b);
     c->pool.clear();
     if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
     n_paths = std::max<size_t>(n_paths, 64);
-    // queues hold slots, not entries: every producer may leave the tail of its last region (<= 8192 slots, and <= 1/16 of the
-    // queue) as holes.  4096 producers (traversal waves / shading workgroups) bound the slack.
-    const size_t n_slots = n_paths + std::max<size_t>(n_paths / 8 + 65536, (size_t)4 << 20);
-    const size_t n_slots_term = n_paths + std::max<size_t>(n_paths / 4 + 65536, (size_t)8 << 20); // two producer groups append here
+    // Queues hold slots, not entries: every producer may leave the tail of its last region as holes.  A traversal wave reserves
+    // max(64, n_in / (8 * waves)) slots at a time and a shading workgroup max(256, n_in / (8 * workgroups)) (region_size in
+    // pt_kernels.hip), so the holes of one queue stay below n/8 + 8192 * 64 (one traversal kernel) or n/8 + 4 * 3072 * 256 (the up to
+    // four surface-class shading kernels that append to the same ray queues); the terminal queue is fed by both groups.  The slack is
+    // a sizing rule, not a safety margin: a producer that finds a queue full diverts to the queue's dump area and the batch fails
+    // with PT_ERR_LIMIT (pt_config.queue_slack shrinks the slack so that tests can see exactly that).
+    const size_t frac = c->cfg.queue_slack ? (c->cfg.queue_slack & 0xffffu) : 128;
+    const size_t fixed = c->cfg.queue_slack ? 0 : ((size_t)4 << 20);
+    const size_t n_slots = n_paths + n_paths * frac / 1024 + fixed;
+    const size_t n_slots_term = n_paths + 2 * (n_paths * frac / 1024 + fixed); // two producer groups append here
+    // test mode: the surface shade queues are SMALLER than the batch (the ray queues cannot be: the camera rays of a batch fill one)
+    const size_t n_slots_shade = (c->cfg.queue_slack & 0x80000000u) ? std::max<size_t>(n_paths * frac / 1024, 64) : n_slots;
+    if (n_slots_term + kQueueDumpSlots >= (1ull << 32)) return fail(c, PT_ERR_LIMIT, "batch too large for 32-bit queue slots");
     c->cap_slots = n_slots;
     c->cap_slots_term = n_slots_term;
     size_t total = 0;
@@ -308,6 +328,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     };
     int r;
     WavefrontBuffers& w = c->wb;
+    const size_t qs = n_slots + kQueueDumpSlots, qs_term = n_slots_term + kQueueDumpSlots; // allocated slots incl. the dump area
 #define TAKE(ptr, bytes)                                  \
     if ((r = take((bytes), (void**)&(ptr)))) return r;
     TAKE(w.st.rec, n_paths * sizeof(DPathRec));
@@ -319,25 +340,35 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     TAKE(w.st.first_id, n_paths * 4);
     for (int k = 0; k < 2; ++k)
     {
-        TAKE(w.rq[k].a, n_slots * 16);
-        TAKE(w.rq[k].b, n_slots * 16);
-        TAKE(w.rq_lchain[k].a, n_slots * 16);
-        TAKE(w.rq_lchain[k].b, n_slots * 16);
-        TAKE(w.lchain_nb[k], n_slots * 16);
-        TAKE(w.q_term[k], n_slots_term * 8);
+        TAKE(w.rq[k].a, qs * 16);
+        TAKE(w.rq[k].b, qs * 16);
+        TAKE(w.rq_lchain[k].a, qs * 16);
+        TAKE(w.rq_lchain[k].b, qs * 16);
+        TAKE(w.lchain_nb[k], qs * 16);
+        TAKE(w.q_term[k], qs_term * 8);
     }
-    TAKE(w.rq_shadow.a, n_slots * 16);
-    TAKE(w.rq_shadow.b, n_slots * 16);
-    TAKE(w.hits, n_slots * 16);
-    TAKE(w.lchain_hit, n_slots * 16);
-    w.q_shade[Q_TERMINAL] = nullptr;
+    TAKE(w.rq_shadow.a, qs * 16);
+    TAKE(w.rq_shadow.b, qs * 16);
+    TAKE(w.hits, qs * 16);
+    TAKE(w.lchain_hit, qs * 16);
+    w.class_mask = 0;
+    w.q_class_slot = 0;
+    uint32_t n_classes = 0;
     for (uint32_t q = 1; q < Q_COUNT; ++q)
     {
-        if (c->class_present[q]) { TAKE(w.q_shade[q], n_slots * 8); }
-        else w.q_shade[q] = nullptr;
+        if (!c->class_present[q]) continue;
+        w.class_mask |= 1u << q;
+        w.q_class_slot |= n_classes << (4u * q);
+        ++n_classes;
     }
+    w.q_stride = (uint32_t)(n_slots_shade + kQueueDumpSlots);
+    TAKE(w.q_shade_base, (size_t)std::max(n_classes, 1u) * 3 * w.q_stride * 16);
     TAKE(w.counters, (size_t)rows * sizeof(Counters));
+    TAKE(w.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4);
 #undef TAKE
+    w.cap_slots = (uint32_t)n_slots;
+    w.cap_slots_shade = (uint32_t)n_slots_shade;
+    w.cap_slots_term = (uint32_t)n_slots_term;
     HIPCHK(c, hipHostMalloc((void**)&c->h_counters, (size_t)rows * sizeof(Counters), hipHostMallocDefault));
     c->cap_paths = n_paths;
     c->cap_rows = rows;
@@ -439,13 +470,16 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     }
 
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
+    HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, s));
     { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU);
     const bool nee = g.enable_nee != 0;
-    // The two NEE launches of a bounce are independent (different rays in, different words out).  The BSDF-sampled one has almost
-    // nothing to do since shading answers the rays that miss the lights' root box (it is all launch latency and tail), so it runs on a
-    // side stream beside the shadow-ray launch; the main stream waits for it before the next closest-hit launch.
+    // The BSDF-sampled NEE launch of a bounce has almost nothing to do since shading answers the rays that miss the lights' root box
+    // (it is all launch latency and tail), and nothing before the next SHADING pass reads its results (the closest-hit kernel leaves
+    // paths that cast such a ray to the terminal queue).  It runs on a high-priority side stream beside the shadow-ray launch and the
+    // next closest-hit launch; the main stream waits for it only before it shades.
     int nee_err = PT_OK;
+    bool side_busy = false;
     auto nee_launches = [&](uint32_t row) {
         const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
         if (timing_all)
@@ -457,8 +491,13 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         if (hipEventRecord(c->ev_fork, s) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
         launch_trace_lchain(c->side_stream, tl_side, wb, row);
         if (hipEventRecord(c->ev_join, c->side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
+        side_busy = true;
         launch_trace_shadow(s, tl, wb, row);
+    };
+    auto join_side = [&]() {
+        if (!side_busy) return;
         if (hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
+        side_busy = false;
     };
     uint32_t last_row = rows - 1;
     for (uint32_t b = 0; b <= g.max_bounces; ++b)
@@ -467,7 +506,11 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         {
             nee_launches(b - 1);
         }
+#if !PT_JOIN_LATE
+        join_side();
+#endif
         { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
+        join_side();
         for (uint32_t q = 0; q < Q_COUNT; ++q)
             if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam, env); }
         // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
@@ -484,6 +527,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     if (nee)
     {
         nee_launches(last_row - 1);
+        join_side();
         { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
     }
     if (nee_err) return fail(c, PT_ERR_HIP, "stream fork/join failed");
@@ -504,11 +548,9 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     for (uint32_t r = 0; r < rows; ++r)
     {
         const Counters& k = c->h_counters[r];
-        // region reservations can never pass the slack the queues were allocated with; if they did, memory was overwritten
-        if (k.n_closest > c->cap_slots || k.n_shadow > c->cap_slots || k.n_lchain > c->cap_slots || k.n_shade[Q_TERMINAL] > c->cap_slots_term)
-            return fail(c, PT_ERR_LIMIT, "internal: queue region reservation exceeded its capacity");
-        for (uint32_t q = 1; q < Q_COUNT; ++q)
-            if (k.n_shade[q] > c->cap_slots) return fail(c, PT_ERR_LIMIT, "internal: shade queue reservation exceeded its capacity");
+        // a producer that found a queue full has diverted its entries to the queue's dump area (nothing was written out of bounds)
+        // and raised this flag: the batch's results are incomplete
+        if (k.overflow) return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
         c->stats.rays_closest += k.valid_closest;
         c->stats.rays_any += (uint64_t)k.valid_shadow + k.n_lchain_hit;
         c->stats.rays_light_closest += (uint64_t)k.valid_lchain + k.culled_lchain; // casts of integrator.rs:100, whoever answered them
@@ -616,8 +658,11 @@ int pt_set_config(pt_ctx* c, const pt_config* cfg)
     std::lock_guard<std::mutex> lk(c->mu);
     const uint32_t old_px = c->local_pixels;
     const int old_dev = c->cfg.device;
+    const pt_config old = c->cfg;
     int r = normalise_config(c, cfg);
     if (r) return r;
+    if (c->cfg.queue_slack != old.queue_slack) c->cap_paths = 0;             // the wavefront pool is sized with it
+    if (c->cfg.stack_lds_levels != old.stack_lds_levels || ((c->cfg.flags ^ old.flags) & PT_FLAG_NO_LDS_SCENE)) c->scene_uploaded = false;
     if (c->dev_ready && cfg->device != old_dev && cfg->device >= 0) return fail(c, PT_ERR_STATE, "device cannot change after first use");
     if (c->local_pixels != old_px)
     {
@@ -1047,11 +1092,12 @@ static int upload_rays(pt_ctx* c, uint32_t n, const float* o, const float* d, co
         b[i] = f4{d[3 * i], d[3 * i + 1], d[3 * i + 2], from_bits(i)};
     }
     int r;
-    if ((r = dev_alloc(c, da, (size_t)n * 16)) || (r = dev_alloc(c, db, (size_t)n * 16)) || (r = dev_alloc(c, dhead, 16))) return r;
+    const size_t head_bytes = (size_t)(32 + kHeadWordsPerQueue) * 4; // word 0 = n, then the queue's zeroed claim cursors
+    if ((r = dev_alloc(c, da, (size_t)n * 16)) || (r = dev_alloc(c, db, (size_t)n * 16)) || (r = dev_alloc(c, dhead, head_bytes))) return r;
     HIPCHK(c, hipMemcpyAsync(da.p, a.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(db.p, b.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    const uint32_t head[4] = {0, n, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(dhead.p, head, 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(dhead.p, 0, head_bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dhead.p, &n, 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }

@@ -12,7 +12,8 @@ struct TraceLaunch
     SceneView scene;
     const void* blob;        // contiguous nodes | tri_isect | instances (device), copied to LDS when lds_scene
     bool lds_scene;
-    uint32_t grid_blocks;    // persistent grid
+    uint32_t grid_blocks;    // upper bound of the persistent grid (the launchers shrink it to what is resident at once)
+    uint32_t n_cus;
     uint32_t block_threads;  // 64..256
 };
 
@@ -24,11 +25,28 @@ struct WavefrontBuffers
     RayQueue rq_lchain[2]; // BSDF-sampled NEE rays, double buffered by bounce parity (the next shading pass re-reads directions)
     f4* lchain_nb[2];     // per BSDF-sampled ray, same slots and parity: bsdf rgb of the sampled direction | weakening
     f4* lchain_hit;       // per BSDF-sampled ray: its lights-TLAS closest hit t,u,v | id, written only when the light is visible
-    f4* hits;             // world closest hits, dense by ray index
-    uint2* q_shade[Q_COUNT]; // entries {ray index, path id}; Q_TERMINAL slot unused (see q_term)
+    f4* hits;             // world closest hits of rays whose path goes to the terminal queue, by ray index (and the unit hooks' output)
+    // surface classes: self-contained hit records in queue order (ShadeQueue).  One allocation for all classes present in the scene:
+    // class q's arrays a, b, c start at q_shade_base + (3 * slot(q) + {0,1,2}) * q_stride, slot(q) = nibble q of q_class_slot
+    // (one base pointer instead of fifteen: the traversal kernels are short of scalar registers)
+    f4* q_shade_base;
+    uint32_t q_stride;     // slots per array (capacity + dump area)
+    uint32_t q_class_slot;
     uint2* q_term[2];     // terminal queue {ray index | path id + ENTRY_DEAD, path id}, double buffered by bounce parity
     Counters* counters;   // [max_bounces + 2]
+    uint32_t* heads;      // [max_bounces + 2][HEADS_PER_ROW][kHeadWordsPerQueue] claim cursors of the ray queues
+    uint32_t cap_slots;   // capacity of every ray queue (each allocated with kQueueDumpSlots more)
+    uint32_t cap_slots_shade; // capacity of the surface shade queues (= cap_slots except in the overflow test)
+    uint32_t cap_slots_term;
+    uint32_t class_mask;  // bit q: the scene has instances of shade class q
 };
+
+inline ShadeQueue shade_queue(const WavefrontBuffers& wb, uint32_t q)
+{
+    const size_t slot = (wb.q_class_slot >> (4u * q)) & 0xfu;
+    f4* a = wb.q_shade_base + 3u * slot * (size_t)wb.q_stride;
+    return ShadeQueue{a, a + wb.q_stride, a + 2u * (size_t)wb.q_stride};
+}
 
 void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb);
 // closest hit against the world TLAS for bounce `b`: reads rq[b&1], writes hits + shade queues of row b
@@ -54,8 +72,9 @@ void launch_post_tonemap(hipStream_t s, uint32_t n, const f4* accum, f4* out);
 void launch_post_rgb8(hipStream_t s, uint32_t n, const f4* accum, uint8_t* out);
 
 // unit hooks
-void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits);
-void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded);
+// n_and_heads: word 0 = number of rays, words [32, 32 + kHeadWordsPerQueue) = zeroed claim cursors
+void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* n_and_heads, f4* hits);
+void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* n_and_heads, uint32_t* occluded);
 void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy);
 void launch_math_probe(hipStream_t s, int fn, uint32_t n, const float* a, const float* b, float* o0, float* o1, uint64_t seed);
 void launch_material_probe(hipStream_t s, const SceneView& sv, int material, uint32_t n, const float* incoming, const float* normal,

@@ -15,6 +15,10 @@
 #include "pt_kernels.h"
 #include "pt_materials.h"
 
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
 namespace pt {
 namespace {
 
@@ -27,6 +31,21 @@ namespace {
 #ifndef PT_STEPS_ANY
 #define PT_STEPS_ANY PT_STEPS_PER_ROUND
 #endif
+#ifndef PT_CHUNK_MAX
+#define PT_CHUNK_MAX 1024
+#endif
+#ifndef PT_CHUNK_DIV
+#define PT_CHUNK_DIV 4
+#endif
+#ifndef PT_TALLY
+#define PT_TALLY 1
+#endif
+#ifndef PT_REGION_MIN
+#define PT_REGION_MIN 64
+#endif
+#ifndef PT_GUIDED
+#define PT_GUIDED 1
+#endif
 constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
 constexpr int kStepsAny = PT_STEPS_ANY;
 constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
@@ -36,45 +55,136 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-// Persistent-thread work fetch.  A single queue-head word sustains only ~88 dequeues/us on MI355X, so a wave claims a
-// private range of rays with ONE atomic and then refills its idle lanes from that range with no further traffic.
+// Persistent-thread work fetch.  A single queue-head word sustains only ~88 dequeues/us on MI355X — 16 k claims take 186 us, which
+// used to be most of a 1 M-ray launch — so:
+//  * the first chunk of every wave is static (wave w owns rays [w*chunk, (w+1)*chunk)): a launch with few rays costs no atomics
+//    at all, and only as many workgroups as the queue has 64-ray chunks take part (the others leave before staging anything);
+//  * the rest of the queue is cut into kQueueHeads partitions with one claim cursor each, every cursor in a cache line of its own
+//    (QueueHeads, pt_types.h).  A wave that runs dry looks at all cursors with ONE 64-lane load, claims a chunk with one atomic
+//    from the first partition at or after its home partition that has one left, and so drifts on to other partitions (steals)
+//    when its own is empty.  "Nothing left anywhere" is seen by that load: no wave ends with an atomic that finds the queue empty;
+//  * with claims this cheap the chunks can be small (n / 4 per wave, 64..1024 rays; same-box sweep: 512/8 the same, 256/16 and
+//    2048/2 worse): the launch ends about one small chunk after the last claim instead of after the slowest wave's two big ones.
+struct FetchPlan
+{
+    uint32_t n;        // rays (queue slots) in the launch
+    uint32_t chunk;    // rays per static chunk, and the most a dynamic claim takes; multiple of 64
+    uint32_t n_static; // slots [0, n_static) are owned statically, chunk by chunk, by the participating waves
+    uint32_t psize;    // slots per dynamic partition, multiple of 64
+    uint32_t guide;    // a dynamic claim takes (what is left of the partition) / guide slots: chunks shrink as the queue drains
+    uint32_t blocks;   // workgroups that take part
+};
+__device__ __forceinline__ FetchPlan fetch_plan(uint32_t n)
+{
+    FetchPlan pl;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t need_waves = (n + 63u) >> 6;
+    pl.blocks = min(gridDim.x, (need_waves + wpb - 1u) / wpb);
+    const uint32_t waves = max(pl.blocks, 1u) * wpb;
+    uint32_t c = n / (waves * (uint32_t)PT_CHUNK_DIV);
+    c = c < 64u ? 64u : (c > (uint32_t)PT_CHUNK_MAX ? (uint32_t)PT_CHUNK_MAX : c);
+    pl.chunk = (c + 63u) & ~63u;
+    pl.n = n;
+    const uint64_t st = (uint64_t)waves * pl.chunk;
+    pl.n_static = st >= n ? n : (uint32_t)st;
+    const uint32_t units = (n - pl.n_static + 63u) >> 6;
+    pl.psize = ((units + kQueueHeads - 1u) / kQueueHeads) << 6;
+    // a partition is shared by waves / kQueueHeads waves on average; each takes half its fair share of what is left
+    pl.guide = max(1u, 2u * waves / kQueueHeads);
+    return pl;
+}
 struct WaveRange
 {
     uint32_t cur, end;
-    bool drained; // the global queue has no chunk left
+    uint32_t home;    // partition this wave tries first
+    uint32_t seen;    // what this wave last knew of its home partition's cursor (sizes the next claim)
+    bool drained;     // the queue has no chunk left for this wave
+    // The claim for the chunk AFTER the current one is issued when the current one is taken up and its answer is looked at only
+    // when the current one runs out, so the atomic's round trip overlaps the traversal instead of stalling the wave (a same-box
+    // A/B of synchronous claims: every halving of the chunk size cost ~2 % of the frame).  A claim that succeeded owns its chunk:
+    // the wave always looks at the answer before it leaves.
+    bool nx_valid;    // a claim is outstanding
+    uint32_t nx_p;    // ... on this partition
+    uint32_t nx_len;  // ... for this many slots
+    uint32_t nx_got;  // ... and this is the atomic's return value (lane 0)
 };
-__device__ __forceinline__ uint32_t fetch_chunk_size(uint32_t n)
+// Guided self-scheduling: a claim takes a fraction of what the claimant believes is left in the partition, between 64 slots and the
+// static chunk size, so the last chunks of a launch are small and the launch ends ~one 64-ray chunk after the queue runs dry.
+__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t seen)
 {
-    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t c = n / (waves * 2u); // two chunks per wave when the queue is short (same-box sweep over 1, 2, 3, 4, 8: 2 is best)
-    c = c < 64u ? 64u : (c > 2048u ? 2048u : c);
-    return (c + 63u) & ~63u;
+#if PT_GUIDED
+    const uint32_t left = seen < pl.psize ? pl.psize - seen : 0u;
+    uint32_t c = (left / pl.guide + 63u) & ~63u;
+    return c < 64u ? 64u : (c > pl.chunk ? pl.chunk : c);
+#else
+    return pl.chunk;
+#endif
 }
-// The first chunk of every wave is static (wave w owns rays [w*chunk, (w+1)*chunk)): a launch with few rays costs no
-// atomics at all and thousands of waves do not pile onto the head word at kernel start.  Later chunks are claimed
-// dynamically and start after the static region.
-__device__ __forceinline__ WaveRange first_range(uint32_t n, uint32_t chunk)
+__device__ __forceinline__ void prefetch_claim(WaveRange& wr, uint32_t* heads, const FetchPlan& pl)
 {
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t lo = (uint64_t)wave * chunk;
+    wr.nx_valid = true;
+    wr.nx_p = wr.home;
+    wr.nx_len = claim_len(pl, wr.seen);
+    if (lane_id() == 0u) wr.nx_got = atomicAdd(heads + wr.home * kHeadStrideWords, wr.nx_len);
+}
+// [start, start + len) of partition p, clipped to the partition and to the queue; false if nothing of it exists
+__device__ __forceinline__ bool take_claim(WaveRange& wr, const FetchPlan& pl, uint32_t p, uint32_t got, uint32_t len)
+{
+    const uint32_t dyn = pl.n - pl.n_static;
+    const uint64_t off = (uint64_t)p * pl.psize + got;
+    if (got >= pl.psize || off >= dyn) return false;
+    const uint64_t stop = min(min(off + len, (uint64_t)(p + 1u) * pl.psize), (uint64_t)dyn);
+    wr.cur = pl.n_static + (uint32_t)off;
+    wr.end = pl.n_static + (uint32_t)stop;
+    return true;
+}
+__device__ __forceinline__ WaveRange first_range(const FetchPlan& pl, uint32_t* heads)
+{
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keep the range in SGPRs
+    const uint64_t lo = (uint64_t)wave * pl.chunk;
     WaveRange wr;
-    wr.drained = lo >= n; // then every dynamic chunk also starts past n
-    wr.cur = lo >= n ? n : (uint32_t)lo;
-    wr.end = min((uint64_t)n, lo + chunk);
+    wr.cur = lo >= pl.n_static ? pl.n : (uint32_t)lo;
+    wr.end = lo >= pl.n_static ? pl.n : (uint32_t)min((uint64_t)pl.n_static, lo + pl.chunk);
+    wr.home = (wave * 7u) & (kQueueHeads - 1u); // neighbouring waves start on different cursors
+    wr.seen = 0u;
+    wr.drained = pl.n_static >= pl.n;            // nothing is handed out dynamically
+    wr.nx_valid = false;
+    wr.nx_p = 0u;
+    wr.nx_len = 0u;
+    wr.nx_got = 0u;
+    if (!wr.drained) prefetch_claim(wr, heads, pl);
     return wr;
 }
 // returns how many of the wave's idle lanes receive a ray; lane i (rank r among idle lanes) gets ray first + r
-__device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, uint32_t n, uint32_t chunk, uint32_t n_idle, uint32_t& first)
+__device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, const FetchPlan& pl, uint32_t n_idle, uint32_t& first)
 {
     if (wr.cur >= wr.end && !wr.drained)
     {
-        const uint64_t static_end = (uint64_t)gridDim.x * (blockDim.x >> 6) * chunk;
-        uint32_t got = 0;
-        if (lane_id() == 0u) got = atomicAdd(head, chunk);
-        got = __shfl(got, 0);
-        const uint64_t base = static_end + got;
-        if (base >= n) { wr.drained = true; wr.cur = wr.end = n; }
-        else { wr.cur = (uint32_t)base; wr.end = (uint32_t)min((uint64_t)n, base + chunk); }
+        bool have = false;
+        if (wr.nx_valid)
+        {
+            const uint32_t got = __builtin_amdgcn_readfirstlane(wr.nx_got);
+            wr.nx_valid = false;
+            wr.seen = got + wr.nx_len;
+            have = take_claim(wr, pl, wr.nx_p, got, wr.nx_len);
+        }
+        const uint32_t l = lane_id();
+        while (!have) // the home partition is empty: look at all cursors; at most kQueueHeads rounds (a failed claim = an empty partition)
+        {
+            const uint32_t h = __hip_atomic_load(heads + l * kHeadStrideWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t m = __ballot(h < pl.psize && (uint64_t)l * pl.psize + h < (uint64_t)(pl.n - pl.n_static));
+            if (m == 0ull) { wr.drained = true; wr.cur = wr.end = pl.n; break; }
+            const uint64_t rot = wr.home == 0u ? m : ((m >> wr.home) | (m << (64u - wr.home)));
+            const uint32_t p = (wr.home + (uint32_t)__builtin_ctzll(rot)) & (kQueueHeads - 1u);
+            const uint32_t len = claim_len(pl, (uint32_t)__builtin_amdgcn_readlane((int)h, (int)p)); // readlane, not a shuffle: the claim state stays in SGPRs
+            uint32_t got = 0;
+            if (l == 0u) got = atomicAdd(heads + p * kHeadStrideWords, len);
+            got = __builtin_amdgcn_readfirstlane(got);
+            wr.home = p;
+            wr.seen = got + len;
+            have = take_claim(wr, pl, p, got, len);
+        }
+        if (!wr.drained) prefetch_claim(wr, heads, pl);
     }
     const uint32_t take = min(n_idle, wr.end - wr.cur);
     first = wr.cur;
@@ -83,30 +193,48 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* head, ui
 }
 
 // Queue appends.  A returning atomic on ONE queue-tail word sustains only some tens of millions of operations per second on
-// MI355X (price list "dequeue"), and a wavefront renderer wants ~10^9 appended entries per second, so nobody appends entry by
+// MI355X (price list "dequeue"), and a wavefront renderer wants ~10^10 appended entries per second, so nobody appends entry by
 // entry or even wave by wave: a producer (a traversal wave, a shading workgroup) RESERVES a private region of the output
 // queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
-// when the producer exits is filled with HOLE markers that consumers skip; the queue's counter therefore counts slots, not
-// entries.  Region size = slots_in / (producers * 16), clamped to [256, 8192]: holes stay below ~6 % of a large queue.
+// when the producer exits is filled with HOLE markers that consumers skip (they come in runs, so skipping them costs a load per
+// 64); the queue's counter therefore counts slots, not entries.  Region size = slots_in / (producers * 8), clamped to [64, 8192],
+// with only the producers that actually take part counted: holes stay below ~1/16 of a large queue and a small launch stays small.
+//
+// Capacity: a reservation that would pass the queue's capacity is diverted to the queue's dump area (kQueueDumpSlots slots past the
+// capacity, shared by everybody who overflows) and raises the batch's overflow flag: nothing is ever stored out of bounds, the
+// host turns the flag into PT_ERR_LIMIT.  Consumers clamp the slot count they read to the capacity.
 enum : uint32_t { PRIMARY_MISS = 0xffu /* PathState::occl: the camera ray left the scene at once (radiance = ambient) */ };
 enum : uint32_t { HOLE = 0xffffffffu, PATH_ENDS = 0x80000000u /* shadow-ray path ids: see k_any */ };
 struct Region { uint32_t cur, end; };
-__device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers)
+// `least`: the most one reservation has to take in one go (64 for a wave, 256 for a workgroup)
+__device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers, uint32_t least)
 {
-    uint32_t r = n_in / (producers * 16u);
-    r = r < 256u ? 256u : (r > 8192u ? 8192u : r);
+    uint32_t r = n_in / (max(producers, 1u) * 8u);
+    r = r < least ? least : (r > kQueueDumpSlots ? (uint32_t)kQueueDumpSlots : r);
     return (r + 63u) & ~63u;
+}
+// one thread: next region of `rsize` slots, or the dump area when the queue is full
+__device__ __forceinline__ uint32_t next_region(const Region& rg, uint32_t* counter, uint32_t rsize, uint32_t cap, uint32_t* overflow)
+{
+    if (rg.end > cap) return cap; // already diverted: stay in the dump area and leave the counter alone (it must not wrap)
+    const uint32_t nb = atomicAdd(counter, rsize);
+    if (cap < rsize || nb > cap - rsize)
+    {
+        __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return cap;
+    }
+    return nb;
 }
 // wave-uniform: take `total` slots; entries ranked below `left` go to base0 + rank, the others to base1 + (rank - left)
 struct Placement { uint32_t base0, left, base1; };
 __device__ __forceinline__ uint32_t place(const Placement& p, uint32_t rank) { return rank < p.left ? p.base0 + rank : p.base1 + (rank - p.left); }
-__device__ __forceinline__ Placement wave_reserve(Region& rg, uint32_t* counter, uint32_t total, uint32_t rsize)
+__device__ __forceinline__ Placement wave_reserve(Region& rg, uint32_t* counter, uint32_t total, uint32_t rsize, uint32_t cap, uint32_t* overflow)
 {
     Placement p{rg.cur, rg.end - rg.cur, 0u};
     if (total > p.left)
     {
         uint32_t nb = 0;
-        if (lane_id() == 0u) nb = atomicAdd(counter, rsize);
+        if (lane_id() == 0u) nb = next_region(rg, counter, rsize, cap, overflow);
         nb = __shfl(nb, 0);
         p.base1 = nb;
         rg.cur = nb + (total - p.left);
@@ -129,7 +257,8 @@ __device__ __forceinline__ void block_append_init(BlockAppend& sh)
     if (threadIdx.x < 4u) sh.region[threadIdx.x] = Region{0u, 0u};
     __syncthreads();
 }
-__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t rsize, uint32_t pos[4])
+__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t rsize, const uint32_t caps[4],
+                                              uint32_t* overflow, uint32_t pos[4])
 {
     const uint32_t wid = threadIdx.x >> 6;
     uint64_t m[4];
@@ -150,7 +279,7 @@ __device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const c
         Placement p{rg.cur, rg.end - rg.cur, 0u};
         if (total > p.left)
         {
-            const uint32_t nb = atomicAdd(counters[q], rsize);
+            const uint32_t nb = next_region(rg, counters[q], rsize, caps[q], overflow);
             p.base1 = nb;
             rg.cur = nb + (total - p.left);
             rg.end = nb + rsize;
@@ -168,6 +297,14 @@ __device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const c
 __device__ __forceinline__ f3 xyz(const f4& v) { return f3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
+
+// Streaming accesses of the shading pass: rays and hit records are written once and read once, by the next kernel, long after the
+// ~200 GB in between have flushed every cache; "nt" accesses keep them from displacing the records and scene tables in L2
+// (same-box A/B: -0.6 ms per frame; the 64-byte path records must NOT be streamed: their four words merge in L2, +4 ms without).
+typedef float nt4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(f4* p, f4 v) { __builtin_nontemporal_store(nt4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4_t*>(p)); }
+__device__ __forceinline__ f4 nt_load(const f4* p) { const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p)); return f4{v.x, v.y, v.z, v.w}; }
+
 
 // AABB::intersect / intersect_t (boundingbox.rs:97-131):
 //   t0 = (min - o) * inv, t1 = (max - o) * inv;  t_small = min(max(t0, EPS), max(t1, EPS));  t_big = max(min(t0, t_max), min(t1, t_max));
@@ -326,9 +463,14 @@ enum { CLOSEST_WORLD = 0, CLOSEST_LIGHTS = 1, CLOSEST_HOOK = 2, CLOSEST_PRIMARY 
 
 struct ClosestOut
 {
-    f4* hits;              // WORLD/HOOK: dense by ray index; LIGHTS: by path id
-    uint2* q_shade[Q_COUNT];   // entries {ray index, path id}
+    f4* hits;              // HOOK: dense by ray index; WORLD/PRIMARY: only rays whose path goes to the terminal queue; LIGHTS: by ray index (slot)
+    f4* q_base;            // surface classes' hit records in queue order: see WavefrontBuffers::q_shade_base
+    uint32_t q_stride, q_class_slot;
+    uint2* q_term;         // terminal queue entries {ray index, path id}
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
+    uint32_t cap_shade, cap_term; // queue capacities (slots)
+    uint32_t class_mask;   // shade classes present in the scene (bit Q_TERMINAL always set)
+    uint32_t* overflow;    // batch-wide "a queue was full" flag
     uint32_t* n_light_hit;
     uint32_t* n_valid;     // rays actually traced (the queue counter counts slots, holes included)
     // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
@@ -400,15 +542,16 @@ struct Stack8<true>
 // ------------------------------------------------------------------------------------------------ closest hit
 template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
-                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
-                                                  const ClosestOut out)
+                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                                  uint32_t* __restrict__ heads, const ClosestOut out)
 {
     extern __shared__ uint4 smem[];
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in));
+    if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
     // per-lane stack of (node, t_enter), [level][thread] in LDS (conflict-free ds_read_b64 / ds_write_b64)
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv);
-    const uint32_t n = *n_ptr;
     const uint32_t prim_bits = sv.prim_bits;
 
     bool active = false, pending = false, ray_finite = false;
@@ -420,49 +563,14 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     bool in_blas = false;
     bool any_phase = false;   // CLOSEST_LIGHTS: the lights-TLAS hit exists, now any-hit against the world (integrator.rs:103)
     uint32_t chain_code = 0u; // 0 light visible, 1 blocked, 2 no light on the ray
-    const uint32_t chunk = fetch_chunk_size(n);
-    WaveRange wr = first_range(n, chunk);
-    // staged material binning (CLOSEST_WORLD): finished rays wait in LDS until ~4 waves' worth can be appended at once
-    constexpr uint32_t kStageCap = 256;
-    uint2* const stage_idx = reinterpret_cast<uint2*>(smem + blob_words) + (size_t)sv.stack_lds * blockDim.x +
-                             (threadIdx.x >> 6) * kStageCap;
-    uint32_t staged = 0, light_hits = 0, valid_rays = 0;
+    WaveRange wr = first_range(plan, heads);
+    // material binning (CLOSEST_WORLD / PRIMARY): a retiring ray's hit record goes straight to its class's shade queue, into a region
+    // of that queue this wave has reserved (wave_reserve: one atomic per region, none per entry)
+    uint32_t light_hits = 0, valid_rays = 0;
     Region bin_region[Q_COUNT];
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
-    const uint32_t rsize = region_size(n, gridDim.x * (blockDim.x >> 6));
-    auto flush_stage = [&]() {
-        uint2 idx[4];
-        uint32_t cls[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j)
-        {
-            const uint32_t k = j * 64u + lane_id();
-            // the class rides in the top bits of the PATH id (path ids are below 2^29, pt_api.cpp; ray indices are queue slots, holes
-            // included, and may use all 32 bits)
-            const uint2 e = k < staged ? stage_idx[k] : make_uint2(0u, 0xffffffffu);
-            idx[j] = make_uint2(e.x, e.y & 0x1fffffffu);
-            cls[j] = e.y >> 29;
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < Q_COUNT; ++c)
-        {
-            uint64_t m[4];
-            uint32_t total = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) { m[j] = __ballot(cls[j] == c); total += (uint32_t)__popcll(m[j]); }
-            if (total == 0u) continue;
-            const Placement pl = wave_reserve(bin_region[c], out.n_shade + c, total, rsize);
-            uint32_t rank0 = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j)
-            {
-                if (cls[j] == c) out.q_shade[c][place(pl, rank0 + mbcnt64(m[j]))] = idx[j];
-                rank0 += (uint32_t)__popcll(m[j]);
-            }
-        }
-        staged = 0;
-    };
+    const uint32_t rsize = region_size(plan.n, plan.blocks * (blockDim.x >> 6), (uint32_t)PT_REGION_MIN);
 
     for (;;)
     {
@@ -547,15 +655,39 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         }
                         qm = __ballot(pending);
                     }
-                    if (pending)
+                    if (qm != 0ull)
                     {
-                        out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
-                        const uint32_t k = staged + mbcnt64(qm);
-                        const uint32_t cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
-                        stage_idx[k] = make_uint2(ray_idx, pid | (cls << 29));
+                        // bin by shade class.  Surface classes get the whole hit record in queue order (the shading pass then reads
+                        // linearly and never gathers by ray index); terminal entries stay {ray index, path id} + hits[ray index].
+                        uint32_t cls = Q_COUNT;
+                        if (pending) cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
+                        const f4 hit{bt, hud / hdet, hvd / hdet, asf(bid)};
+#pragma unroll
+                        for (uint32_t c = 0; c < Q_COUNT; ++c)
+                        {
+                            if (!((out.class_mask >> c) & 1u)) continue;
+                            const uint64_t m = __ballot(cls == c);
+                            if (m == 0ull) continue;
+                            const Placement pl = wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize,
+                                                              c == Q_TERMINAL ? out.cap_term : out.cap_shade, out.overflow);
+                            if (cls == c)
+                            {
+                                const uint32_t pos = place(pl, mbcnt64(m));
+                                if (c == Q_TERMINAL)
+                                {
+                                    out.hits[ray_idx] = hit;
+                                    out.q_term[pos] = make_uint2(ray_idx, pid);
+                                }
+                                else
+                                {
+                                    f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride + pos;
+                                    nt_store(qa, f4{w.d.x, w.d.y, w.d.z, asf(pid)});
+                                    nt_store(qa + out.q_stride, hit);
+                                    if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)out.q_stride, f4{w.o.x, w.o.y, w.o.z, 0.0f});
+                                }
+                            }
+                        }
                     }
-                    staged += (uint32_t)__popcll(qm);
-                    if (staged > kStageCap - 64u) flush_stage();
                 }
                 else if (MODE == CLOSEST_LIGHTS)
                 {
@@ -575,7 +707,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             // ---- refill idle lanes from the wave's private range
             const uint64_t idle = ~act;
             uint32_t first;
-            const uint32_t take = claim_rays(wr, head, n, chunk, (uint32_t)__popcll(idle), first);
+            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(idle), first);
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
@@ -781,24 +913,28 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     }
     if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
     {
-        if (staged != 0u) flush_stage();
-        // hand back what is left of this wave's regions as holes
+        // hand back what is left of this wave's regions as holes (a hole is a path id of HOLE)
+        const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
+        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) out.q_term[i] = make_uint2(HOLE, 0u);
 #pragma unroll
-        for (uint32_t c = 0; c < Q_COUNT; ++c)
-            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) out.q_shade[c][i] = make_uint2(HOLE, 0u);
+        for (uint32_t c = 1; c < Q_COUNT; ++c)
+        {
+            f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride;
+            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
+        }
     }
     if (MODE != CLOSEST_HOOK)
     {
         uint32_t total = valid_rays;
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (total != 0u && lane_id() == 0u) atomicAdd(out.n_valid, total);
+        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(out.n_valid, total);
     }
     if (MODE == CLOSEST_LIGHTS)
     {
         // any-hit casts of integrator.rs:103 (per-lane tallies, one atomic per wave)
         uint32_t total = light_hits;
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (total != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, total);
+        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, total);
     }
 }
 
@@ -812,14 +948,16 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 // on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
 template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
-                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ head,
-                                              uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid, f4* __restrict__ radiance)
+                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid,
+                                              f4* __restrict__ radiance)
 {
     extern __shared__ uint4 smem[];
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in));
+    if (blockIdx.x >= plan.blocks) return;
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv); // entries (node, entry distance of its box)
-    const uint32_t n = *n_ptr;
 
     bool active = false, ray_finite = false;
     uint32_t out_idx = 0, valid_rays = 0;
@@ -850,8 +988,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
         else occluded[out_idx] = v;
     };
     bool in_blas = false;
-    const uint32_t chunk = fetch_chunk_size(n);
-    WaveRange wr = first_range(n, chunk);
+    WaveRange wr = first_range(plan, heads);
 
     for (;;)
     {
@@ -863,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
             if (no_more) break;
             const uint64_t idle = ~act;
             uint32_t first;
-            const uint32_t take = claim_rays(wr, head, n, chunk, (uint32_t)__popcll(idle), first);
+            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(idle), first);
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
@@ -958,7 +1095,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
     {
         uint32_t total = valid_rays;
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (total != 0u && lane_id() == 0u) atomicAdd(n_valid, total);
+        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(n_valid, total);
     }
 }
 
@@ -1018,13 +1155,6 @@ __global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const C
     // no state is initialised: bounce 0 knows path_weight = 1, accumulated = 0, one draw consumed (integrator.rs:153-161)
 }
 
-// Streaming accesses of the shading pass: rays and hit records are written once and read once, by the next kernel, long after the
-// ~200 GB in between have flushed every cache; "nt" accesses keep them from displacing the records and scene tables in L2
-// (same-box A/B: -0.6 ms per frame; the 64-byte path records must NOT be streamed: their four words merge in L2, +4 ms without).
-typedef float nt4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void nt_store(f4* p, f4 v) { __builtin_nontemporal_store(nt4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4_t*>(p)); }
-__device__ __forceinline__ f4 nt_load(const f4* p) { const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p)); return f4{v.x, v.y, v.z, v.w}; }
-
 struct ShadeIO
 {
     PathState st;
@@ -1032,9 +1162,11 @@ struct ShadeIO
     f4* lchain_nb;            // this bounce's BSDF-sampled rays: bsdf rgb | weakening, by rq_lchain slot
     const f4* lchain_nb_prev; // last bounce's
     const f4* lchain_hit;     // last bounce's light hits, by rq_lchain_prev slot
-    const f4* hits;
-    const uint2* entries;
+    const f4* hits;           // terminal pass only: hits of the rays that went to the terminal queue, by ray index
+    const uint2* entries;     // terminal pass: {ray index | ENTRY_DEAD, path id}
+    ShadeQueue q_in;          // surface pass: this class's hit records in queue order
     uint2* q_term_next;
+    uint32_t cap_slots, cap_slots_term, cap_slots_shade; // queue capacities (slots)
     Counters* ctr;     // row of this bounce
     Counters* ctr_next;
     f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
@@ -1103,7 +1235,7 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
 // Q_TERMINAL: misses (integrator.rs:254-269), emissive hits (:207-214) and paths that already ended but still owe an NEE resolve.
 __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
-    const uint32_t n = io.ctr->n_shade[Q_TERMINAL];
+    const uint32_t n = min(io.ctr->n_shade[Q_TERMINAL], io.cap_slots_term);
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
     {
         const uint2 e2 = io.entries[idx];
@@ -1168,20 +1300,22 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
 {
     __shared__ BlockAppend sh_append;
     block_append_init(sh_append);
-    const uint32_t n = io.ctr->n_shade[QCLASS];
-    const uint32_t rsize = region_size(n, gridDim.x);
+    const uint32_t n = min(io.ctr->n_shade[QCLASS], io.cap_slots_shade);
+    const uint32_t rsize = region_size(n, min(gridDim.x, (n + blockDim.x - 1u) / blockDim.x), 256u);
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     uint32_t culled = 0;
-    // the queue entry of the NEXT iteration is fetched one iteration ahead: the loads that depend on it (ray, hit, path record) then
-    // start as soon as an iteration begins instead of one memory round trip later
+    // Everything this pass needs of a hit arrives in queue order (ShadeQueue): direction | path id, t u v | hit id, origin.  The first
+    // word of the NEXT iteration is fetched one iteration ahead, so the path-record load that depends on its path id starts as soon
+    // as an iteration begins instead of one memory round trip later.
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    uint2 e_next = idx < n ? io.entries[idx] : make_uint2(HOLE, 0u);
+    const f4 hole_a{0.0f, 0.0f, 0.0f, asf(HOLE)};
+    f4 a_next = idx < n ? nt_load(io.q_in.a + idx) : hole_a;
     for (; idx < total; idx += stride)
     {
-        const uint2 e2 = e_next;
-        e_next = (idx + stride) < n ? io.entries[idx + stride] : make_uint2(HOLE, 0u);
-        bool valid = e2.x != HOLE;
+        const f4 rb = a_next;
+        a_next = (idx + stride) < n ? nt_load(io.q_in.a + idx + stride) : hole_a;
+        bool valid = asu(rb.w) != HOLE;
         bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
         uint32_t pid = 0, flags = 0;
@@ -1190,10 +1324,9 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         uint32_t draws = 0;
         if (valid)
         {
-            const uint32_t entry = e2.x;
-            pid = e2.y; // carried in the queue entry so that the state loads do not wait for the ray record
-            const f4 ra = bounce == 0u ? io.primary_a : nt_load(io.rq_in.a + entry);
-            const f4 rb = nt_load(io.rq_in.b + entry), hit = nt_load(io.hits + entry);
+            pid = asu(rb.w);
+            const f4 hit = nt_load(io.q_in.b + idx);
+            const f4 ra = bounce == 0u ? io.primary_a : nt_load(io.q_in.c + idx);
             f4 pw4{1.0f, 1.0f, 1.0f, asf(1u)}; // bounce 0: path_weight = 1, accumulated = 0, the seed draw consumed
             acc = f3{0.0f, 0.0f, 0.0f};
             flags = 0u;
@@ -1426,8 +1559,9 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         // ---- block-aggregated queue appends (every thread of the block reaches this): one atomic per queue per block
         uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
         const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
+        const uint32_t caps[4] = {io.cap_slots, io.cap_slots, io.cap_slots, io.cap_slots_term};
         uint32_t pos[4];
-        block_append4(sh_append, ctrs, preds, rsize, pos);
+        block_append4(sh_append, ctrs, preds, rsize, caps, &io.ctr->overflow, pos);
         if (want_shadow) { nt_store(io.rq_shadow.a + pos[0], sh_a); nt_store(io.rq_shadow.b + pos[0], sh_b); }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
         if (want_next) { nt_store(io.rq_out.a + pos[2], nx_a); nt_store(io.rq_out.b + pos[2], nx_b); }
@@ -1490,13 +1624,26 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
     if (lp >= rp.local_pixels) return;
     f4 a = accum[lp];
     uint32_t idv = id[lp];
-    for (uint32_t s = 0; s < rp.batch_samples; ++s)
+    // eight samples' loads in flight at a time (the sum must be taken in sample order, the loads need not wait for each other)
+    constexpr uint32_t G = 8;
+    for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += G)
     {
-        const uint32_t pid = s * rp.local_pixels + lp;
-        const f3 c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
-        a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
-        // (id << 16) | new once per sample: only the last two samples survive in 32 bits
-        if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
+        uint32_t oc[G];
+        f4 rad[G];
+#pragma unroll
+        for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.local_pixels + lp] : (uint32_t)PRIMARY_MISS;
+#pragma unroll
+        for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.local_pixels + lp] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+#pragma unroll
+        for (uint32_t j = 0; j < G; ++j)
+        {
+            if ((s0 + j) >= rp.batch_samples) break;
+            const uint32_t pid = (s0 + j) * rp.local_pixels + lp;
+            const f3 c = finalise(xyz(rad[j]));
+            a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
+            // (id << 16) | new once per sample: only the last two samples survive in 32 bits
+            if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
+        }
     }
     if (add_to_accum) accum[lp] = a;
     id[lp] = idv;
@@ -1561,11 +1708,10 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
     o[8] = (float)(rng.k - draws);
 }
 
-size_t trace_lds_bytes(const TraceLaunch& tl, bool closest)
+size_t trace_lds_bytes(const TraceLaunch& tl)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
-    const size_t stage = closest ? (size_t)(tl.block_threads / 64) * 256 * 8 : 0; // per-wave binning stage (k_closest)
-    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8 + stage;
+    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8;
 }
 
 } // namespace
@@ -1577,31 +1723,68 @@ void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& ca
     hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.rq[0], wb.counters);
 }
 
-template <int MODE>
-static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
-                                const ClosestOut& out)
+// A persistent grid must be RESIDENT: workgroups that the device cannot hold at once start only when others have left, and by then
+// the queue's dynamic part is gone and the late-comers' static chunks are the launch's tail.  So the grid is what the kernel's
+// registers and LDS allow per CU (asked of the runtime once per kernel variant and LDS size), times the CU count, capped by
+// tl.grid_blocks (the spill area is sized for that).
+#ifndef PT_RESIDENT_GRID
+#define PT_RESIDENT_GRID 1
+#endif
+template <typename K>
+static uint32_t resident_grid(K kernel, const TraceLaunch& tl, size_t lds)
 {
-    const size_t lds = trace_lds_bytes(tl, true);
+#if PT_RESIDENT_GRID
+    struct Key { const void* f; uint32_t threads; size_t lds; int dev; int per_cu; };
+    static std::mutex mu;
+    static std::vector<Key> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Key& k : cache)
+        if (k.f == (const void*)kernel && k.threads == tl.block_threads && k.lds == lds && k.dev == dev) return std::min<uint32_t>(tl.grid_blocks, tl.n_cus * (uint32_t)k.per_cu);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)tl.block_threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache.push_back(Key{(const void*)kernel, tl.block_threads, lds, dev, per_cu});
+    return std::min<uint32_t>(tl.grid_blocks, tl.n_cus * (uint32_t)per_cu);
+#else
+    return tl.grid_blocks;
+#endif
+}
+
+template <int MODE>
+static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t cap_in,
+                                uint32_t* heads, const ClosestOut& out)
+{
+    const size_t lds = trace_lds_bytes(tl);
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
-    const dim3 grid(tl.grid_blocks), block(tl.block_threads);
+    const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
-    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_closest<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
-    else if (tl.lds_scene) hipLaunchKernelGGL((k_closest<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
-    else if (!spill) hipLaunchKernelGGL((k_closest<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
-    else hipLaunchKernelGGL((k_closest<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, out);
+#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, out)
+    if (tl.lds_scene && !spill) PT_LAUNCH((k_closest<true, MODE, false>));
+    else if (tl.lds_scene) PT_LAUNCH((k_closest<true, MODE, true>));
+    else if (!spill) PT_LAUNCH((k_closest<false, MODE, false>));
+    else PT_LAUNCH((k_closest<false, MODE, true>));
+#undef PT_LAUNCH
 }
 template <int MODE>
-static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t* head,
-                            uint32_t* occluded, uint32_t* n_valid, f4* radiance = nullptr)
+static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t cap_in,
+                            uint32_t* heads, uint32_t* occluded, uint32_t* n_valid, f4* radiance = nullptr)
 {
-    const size_t lds = trace_lds_bytes(tl, false);
+    const size_t lds = trace_lds_bytes(tl);
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
-    const dim3 grid(tl.grid_blocks), block(tl.block_threads);
+    const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
-    if (tl.lds_scene && !spill) hipLaunchKernelGGL((k_any<true, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
-    else if (tl.lds_scene) hipLaunchKernelGGL((k_any<true, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
-    else if (!spill) hipLaunchKernelGGL((k_any<false, MODE, false>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
-    else hipLaunchKernelGGL((k_any<false, MODE, true>), grid, block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, head, occluded, n_valid, radiance);
+#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, occluded, n_valid, radiance)
+    if (tl.lds_scene && !spill) PT_LAUNCH((k_any<true, MODE, false>));
+    else if (tl.lds_scene) PT_LAUNCH((k_any<true, MODE, true>));
+    else if (!spill) PT_LAUNCH((k_any<false, MODE, false>));
+    else PT_LAUNCH((k_any<false, MODE, true>));
+#undef PT_LAUNCH
+}
+
+static uint32_t* row_heads(const WavefrontBuffers& wb, uint32_t row, uint32_t which)
+{
+    return wb.heads + ((size_t)row * HEADS_PER_ROW + which) * kHeadWordsPerQueue;
 }
 
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
@@ -1610,9 +1793,15 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     Counters* row = wb.counters + b;
     ClosestOut out{};
     out.hits = wb.hits;
-    for (uint32_t c = 0; c < Q_COUNT; ++c) out.q_shade[c] = wb.q_shade[c];
-    out.q_shade[Q_TERMINAL] = wb.q_term[b & 1u];
+    out.q_base = wb.q_shade_base;
+    out.q_stride = wb.q_stride;
+    out.q_class_slot = wb.q_class_slot;
+    out.q_term = wb.q_term[b & 1u];
     out.n_shade = row->n_shade;
+    out.cap_shade = wb.cap_slots_shade;
+    out.cap_term = wb.cap_slots_term;
+    out.class_mask = wb.class_mask | (1u << Q_TERMINAL);
+    out.overflow = &row->overflow;
     out.n_light_hit = nullptr;
     out.n_valid = &row->valid_closest;
     if (b == 0u)
@@ -1625,7 +1814,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         out.keep_id_from = rp.keep_id_from;
         out.keep_pos_from = rp.keep_pos_from;
         out.finalize_miss = env.w == 0u ? 1u : 0u;
-        launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, &row->head_closest, out);
+        launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, wb.cap_slots, row_heads(wb, b, HEADS_CLOSEST), out);
     }
     else
     {
@@ -1633,13 +1822,14 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         out.radiance = wb.st.radiance;
         out.enable_nee = rp.enable_nee;
         out.finalize_miss = env.w == 0u ? 1u : 0u;
-        launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, &row->head_closest, out);
+        launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, wb.cap_slots, row_heads(wb, b, HEADS_CLOSEST), out);
     }
 }
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
-    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, &row->head_shadow, reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow, wb.st.radiance);
+    launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, wb.cap_slots, row_heads(wb, b, HEADS_SHADOW),
+                                reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow, wb.st.radiance);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -1651,7 +1841,7 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     out.n_valid = &row->valid_lchain;
     out.world_root = tl.scene.world_root;
     out.occl = wb.st.occl;
-    launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, &row->head_lchain, out);
+    launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, wb.cap_slots, row_heads(wb, b, HEADS_LCHAIN), out);
 }
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
                   uint32_t grid_blocks, const CameraView& cam, const EnvView& env)
@@ -1669,8 +1859,12 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.lchain_nb_prev = wb.lchain_nb[(b + 1u) & 1u];
     io.lchain_hit = wb.lchain_hit;
     io.hits = wb.hits;
-    io.entries = qclass == Q_TERMINAL ? wb.q_term[b & 1u] : wb.q_shade[qclass];
+    io.entries = wb.q_term[b & 1u];
+    if (qclass != Q_TERMINAL) io.q_in = shade_queue(wb, qclass);
     io.q_term_next = wb.q_term[(b + 1u) & 1u];
+    io.cap_slots = wb.cap_slots;
+    io.cap_slots_term = wb.cap_slots_term;
+    io.cap_slots_shade = wb.cap_slots_shade;
     io.ctr = wb.counters + b;
     io.ctr_next = wb.counters + b + 1u;
     switch (qclass)
@@ -1708,18 +1902,15 @@ void launch_store_samples(hipStream_t s, const RenderParams& rp, const Wavefront
     hipLaunchKernelGGL(k_store_samples, dim3(blocks), dim3(256), 0, s, rp, wb.st, out);
 }
 
-void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, f4* hits)
+void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* n_and_heads, f4* hits)
 {
-    // head[0] = cursor (zeroed by the caller), head[1] = n
-    (void)n;
     ClosestOut out{};
     out.hits = hits;
-    launch_closest_impl<CLOSEST_HOOK>(s, tl, root, rq, head + 1, head, out);
+    launch_closest_impl<CLOSEST_HOOK>(s, tl, root, rq, n_and_heads, n, n_and_heads + 32, out);
 }
-void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* head, uint32_t* occluded)
+void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* n_and_heads, uint32_t* occluded)
 {
-    (void)n;
-    launch_any_impl<ANY_HOOK>(s, tl, root, rq, head + 1, head, occluded, nullptr);
+    launch_any_impl<ANY_HOOK>(s, tl, root, rq, n_and_heads, n, n_and_heads + 32, occluded, nullptr);
 }
 void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy)
 {

@@ -93,11 +93,12 @@ enum : uint32_t { INSTANCE_IDENTITY = 0x100u }; // inverse matrix is bit-exactly
 struct Counters
 {
     uint32_t n_closest;      // rays in the world closest-hit queue of this bounce
-    uint32_t head_closest;   // persistent-thread fetch cursor
+    uint32_t overflow;       // non-zero: some producer found a queue full (its entries went to the queue's dump area, nothing was
+                             // written out of bounds); the batch is void and the host reports PT_ERR_LIMIT
     uint32_t n_shadow;       // explicit-light shadow rays produced by this bounce's shading
-    uint32_t head_shadow;
+    uint32_t spare0;
     uint32_t n_lchain;       // BSDF-sampled NEE rays (lights TLAS closest hit, then world any hit)
-    uint32_t head_lchain;
+    uint32_t spare1;
     uint32_t valid_lchain;   // BSDF-sampled NEE rays actually traced (queue counters count slots, holes included)
     uint32_t n_lchain_hit;   // of those, how many hit a light (= any-hit casts of integrator.rs:103)
     uint32_t n_shade[Q_COUNT];
@@ -207,6 +208,26 @@ struct RayQueue
 {
     f4* a;
     f4* b;
+};
+
+// Claim cursors of a ray queue.  A returning atomic on ONE word sustains only ~88 operations per microsecond on MI355X, so the part of
+// a queue that is handed out dynamically is cut into kQueueHeads partitions, each with a cursor in a cache line of its own; a wave
+// looks at all cursors with one 64-lane load, takes a chunk from the first partition at or after its home that has one left, and
+// moves on (steals) when its home runs dry.  Zeroed with the counters once per batch.
+enum : uint32_t { kQueueHeads = 64u, kHeadStrideWords = 32u, kHeadWordsPerQueue = kQueueHeads * kHeadStrideWords };
+enum : uint32_t { HEADS_CLOSEST = 0, HEADS_SHADOW = 1, HEADS_LCHAIN = 2, HEADS_PER_ROW = 3 };
+// every queue is allocated with this many slots past its capacity: a producer that finds the queue full diverts its writes there
+// (see wave_reserve) instead of past the end
+enum : uint32_t { kQueueDumpSlots = 8192u };
+
+// Shade queue of one surface class: what the shading pass needs of a hit, written by the traversal kernel in queue order and read
+// back linearly (no gather by ray index):  a = direction.xyz | path id,  b = t, u, v | hit id,  c = origin.xyz | unused.
+// `c` is not written at bounce 0 (every camera ray starts at the eye).  A slot whose path id is HOLE is skipped.
+struct ShadeQueue
+{
+    f4* a;
+    f4* b;
+    f4* c;
 };
 
 } // namespace pt

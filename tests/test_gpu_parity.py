@@ -343,6 +343,25 @@ def test_spilling_stacks_do_not_race_between_concurrent_launches(api, oracle_mod
     assert_bit_equal(g, c, "spill-everything traversal with concurrent NEE launches")
 
 
+def test_full_queue_is_reported_not_overrun(api, oracle_mod):
+    """pt_config.queue_slack in test mode: the ray / shade queues hold only half as many slots as the batch has paths, in a
+    scene where two thirds of the camera rays hit a surface and go on, so reservations find their queue full.  The producers
+    divert to the queue's dump area and raise the overflow flag; the render returns PT_ERR_LIMIT; a context next to it (whose
+    buffers are neighbours in HBM) still renders the right image; and the same context works again once the slack is restored."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Camera, SceneDesc
+    sc = SceneDesc.new(scenes.cornell_models(), Camera.new((0.0, 50.0, 700.0), (0.0, 50.0, 0.0), 60.0, 1.0), "close")
+    good = api.Renderer(sc, 256, 256, max_bounces=6)
+    want = good.render_samples(0, 4)
+    tight = api.Renderer(sc, 256, 256, max_bounces=6, queue_slack=0x80000000 | 512)
+    with pytest.raises(api.PtError) as e:
+        tight.render(0, 16)
+    assert e.value.code == -5 and "queue" in str(e.value)
+    assert_bit_equal(good.render_samples(0, 4), want, "neighbouring context after the overflow")
+    tight.set_config(queue_slack=0)
+    assert_bit_equal(tight.render_samples(0, 4), want, "same context with the default slack")
+
+
 def test_scene_edit_adds_a_material_class(api, oracle_mod):
     """render, add a model of a material class the context has not seen (its shade queue does not exist yet), rebuild, render again"""
     from path_tracer_amd import scenes

@@ -24,10 +24,10 @@ using namespace pt;
 #define PT_SHADE_BLOCKS_PER_CU 12  // persistent shading workgroups per CU (same-box sweep over 4, 6, 8, 12, 16)
 #endif
 #ifndef PT_JOIN_LATE
-#define PT_JOIN_LATE 1
+#define PT_JOIN_LATE 0  // same-box A/B: joining the side stream only before the shading pass costs +2 ms per frame (the two traversal kernels fight for wave slots), 0.1 ms less for a 1/8 share
 #endif
 #ifndef PT_SIDE_PRIORITY
-#define PT_SIDE_PRIORITY 1
+#define PT_SIDE_PRIORITY 0
 #endif
 #ifndef PT_TRACE_BLOCKS_PER_CU_MAX
 #define PT_TRACE_BLOCKS_PER_CU_MAX 8
@@ -84,6 +84,7 @@ struct pt_ctx
     std::vector<DevBuf> pool;
     WavefrontBuffers wb{};
     Counters* h_counters = nullptr; // pinned
+    uint32_t* h_heads = nullptr;    // pinned mirror of the claim-cursor lines (they carry the exact ray tallies)
 
     // stats
     pt_stats stats{};
@@ -300,6 +301,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     for (DevBuf& b : c->pool) dev_free(b);
     c->pool.clear();
     if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
+    if (c->h_heads) { (void)hipHostFree(c->h_heads); c->h_heads = nullptr; }
     n_paths = std::max<size_t>(n_paths, 64);
     // Queues hold slots, not entries: every producer may leave the tail of its last region as holes.  A traversal wave reserves
     // max(64, n_in / (8 * waves)) slots at a time and a shading workgroup max(256, n_in / (8 * workgroups)) (region_size in
@@ -370,6 +372,7 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     w.cap_slots_shade = (uint32_t)n_slots_shade;
     w.cap_slots_term = (uint32_t)n_slots_term;
     HIPCHK(c, hipHostMalloc((void**)&c->h_counters, (size_t)rows * sizeof(Counters), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipHostMallocDefault));
     c->cap_paths = n_paths;
     c->cap_rows = rows;
     c->stats.state_bytes = total;
@@ -543,6 +546,7 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_heads, wb.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     for (uint32_t r = 0; r < rows; ++r)
@@ -551,9 +555,21 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
         // a producer that found a queue full has diverted its entries to the queue's dump area (nothing was written out of bounds)
         // and raised this flag: the batch's results are incomplete
         if (k.overflow) return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
-        c->stats.rays_closest += k.valid_closest;
-        c->stats.rays_any += (uint64_t)k.valid_shadow + k.n_lchain_hit;
-        c->stats.rays_light_closest += (uint64_t)k.valid_lchain + k.culled_lchain; // casts of integrator.rs:100, whoever answered them
+    }
+    // exact tallies live beside the claim cursors, one per cursor line (64 addresses per queue instead of one: a launch of a few
+    // thousand waves that each add to ONE word spends ~50 us on that alone)
+    for (uint32_t r = 0; r < rows; ++r)
+    {
+        const uint32_t* hrow = c->h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
+        for (uint32_t g = 0; g < kQueueHeads; ++g)
+        {
+            const uint32_t* cl = hrow + HEADS_CLOSEST * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* sh = hrow + HEADS_SHADOW * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* lc = hrow + HEADS_LCHAIN * kHeadWordsPerQueue + g * kHeadStrideWords;
+            c->stats.rays_closest += cl[HEAD_TALLY0];
+            c->stats.rays_any += (uint64_t)sh[HEAD_TALLY0] + lc[HEAD_TALLY1];
+            c->stats.rays_light_closest += (uint64_t)lc[HEAD_TALLY0] + lc[HEAD_TALLY2]; // casts of integrator.rs:100, whoever answered them
+        }
     }
     c->stats.paths += rp.n_paths;
     harvest_events(c);
@@ -641,6 +657,7 @@ void pt_destroy(pt_ctx* c)
         DevBuf* bufs[] = {&c->d_input, &c->d_velocity, &c->d_output, &c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_spill, &c->d_accum, &c->d_position, &c->d_id};
         for (DevBuf* b : bufs) dev_free(*b);
         if (c->h_counters) (void)hipHostFree(c->h_counters);
+        if (c->h_heads) (void)hipHostFree(c->h_heads);
         for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
@@ -1313,9 +1330,23 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
 int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows)
 {
     if (!c || !rows16 || !n_rows) return PT_ERR_ARG;
-    if (!c->h_counters) return PT_ERR_STATE;
+    if (!c->h_counters || !c->h_heads) return PT_ERR_STATE;
     const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
     std::memcpy(rows16, c->h_counters, (size_t)rows * sizeof(Counters));
+    for (uint32_t r = 0; r < rows; ++r)
+    {
+        uint32_t* o = rows16 + 16 * r;
+        o[1] = o[3] = o[5] = 0;
+        o[6] = o[7] = o[13] = o[14] = o[15] = 0;
+        const uint32_t* hrow = c->h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
+        for (uint32_t g = 0; g < kQueueHeads; ++g)
+        {
+            const uint32_t* cl = hrow + HEADS_CLOSEST * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* sh = hrow + HEADS_SHADOW * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* lc = hrow + HEADS_LCHAIN * kHeadWordsPerQueue + g * kHeadStrideWords;
+            o[6] += lc[HEAD_TALLY0]; o[7] += lc[HEAD_TALLY1]; o[13] += cl[HEAD_TALLY0]; o[14] += sh[HEAD_TALLY0]; o[15] += lc[HEAD_TALLY2];
+        }
+    }
     *n_rows = rows;
     return PT_OK;
 }

@@ -43,9 +43,6 @@ namespace {
 #ifndef PT_REGION_MIN
 #define PT_REGION_MIN 64
 #endif
-#ifndef PT_GUIDED
-#define PT_GUIDED 1
-#endif
 constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
 constexpr int kStepsAny = PT_STEPS_ANY;
 constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
@@ -108,18 +105,7 @@ struct WaveRange
     uint32_t nx_len;  // ... for this many slots
     uint32_t nx_got;  // ... and this is the atomic's return value (lane 0)
 };
-// Guided self-scheduling: a claim takes a fraction of what the claimant believes is left in the partition, between 64 slots and the
-// static chunk size, so the last chunks of a launch are small and the launch ends ~one 64-ray chunk after the queue runs dry.
-__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t seen)
-{
-#if PT_GUIDED
-    const uint32_t left = seen < pl.psize ? pl.psize - seen : 0u;
-    uint32_t c = (left / pl.guide + 63u) & ~63u;
-    return c < 64u ? 64u : (c > pl.chunk ? pl.chunk : c);
-#else
-    return pl.chunk;
-#endif
-}
+__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t) { return pl.chunk; } // (shrinking claims towards the end of a partition: +1 ms per frame, no gain for a 1/8 share)
 __device__ __forceinline__ void prefetch_claim(WaveRange& wr, uint32_t* heads, const FetchPlan& pl)
 {
     wr.nx_valid = true;
@@ -190,6 +176,15 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, c
     first = wr.cur;
     wr.cur += take;
     return take;
+}
+
+// exact count of what a wave processed, added to the cursor line of its home partition (64 addresses per queue instead of one)
+__device__ __forceinline__ void add_tally(uint32_t* heads, uint32_t per_lane, uint32_t word)
+{
+    uint32_t total = per_lane;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (total != 0u && lane_id() == 0u) atomicAdd(heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords + word, total);
 }
 
 // Queue appends.  A returning atomic on ONE queue-tail word sustains only some tens of millions of operations per second on
@@ -471,8 +466,6 @@ struct ClosestOut
     uint32_t cap_shade, cap_term; // queue capacities (slots)
     uint32_t class_mask;   // shade classes present in the scene (bit Q_TERMINAL always set)
     uint32_t* overflow;    // batch-wide "a queue was full" flag
-    uint32_t* n_light_hit;
-    uint32_t* n_valid;     // rays actually traced (the queue counter counts slots, holes included)
     // CLOSEST_LIGHTS (fused NEE chain): world root for the follow-up any-hit, result codes by path id
     uint32_t world_root;
     uint8_t* occl;
@@ -923,19 +916,9 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
             for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
         }
     }
-    if (MODE != CLOSEST_HOOK)
-    {
-        uint32_t total = valid_rays;
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(out.n_valid, total);
-    }
-    if (MODE == CLOSEST_LIGHTS)
-    {
-        // any-hit casts of integrator.rs:103 (per-lane tallies, one atomic per wave)
-        uint32_t total = light_hits;
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(out.n_light_hit, total);
-    }
+    if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
+    // any-hit casts of integrator.rs:103
+    if (MODE == CLOSEST_LIGHTS) add_tally(heads, light_hits, HEAD_TALLY1);
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
@@ -949,7 +932,7 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
-                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded, uint32_t* __restrict__ n_valid,
+                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                               f4* __restrict__ radiance)
 {
     extern __shared__ uint4 smem[];
@@ -1091,12 +1074,7 @@ __global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __
             }
         }
     }
-    if (n_valid != nullptr)
-    {
-        uint32_t total = valid_rays;
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-        if (PT_TALLY && total != 0u && lane_id() == 0u) atomicAdd(n_valid, total);
-    }
+    if (MODE == ANY_SHADOW) add_tally(heads, valid_rays, HEAD_TALLY0);
 }
 
 // ------------------------------------------------------------------------------------------------ path bookkeeping
@@ -1168,6 +1146,7 @@ struct ShadeIO
     uint2* q_term_next;
     uint32_t cap_slots, cap_slots_term, cap_slots_shade; // queue capacities (slots)
     Counters* ctr;     // row of this bounce
+    uint32_t* lchain_heads; // cursor lines of this bounce's BSDF-sampled NEE queue (the culled tally goes there)
     Counters* ctr_next;
     f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
     EnvView env;       // equirect environment for misses (w == 0: constant ambient, integrator.rs:263-266)
@@ -1596,11 +1575,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
 #undef PT_QUAD_STORE
         }
     }
-    {
-        uint32_t t = culled;
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-        if (t != 0u && lane_id() == 0u) atomicAdd(&io.ctr->culled_lchain, t);
-    }
+    add_tally(io.lchain_heads, culled, HEAD_TALLY2);
     // hand back what is left of this workgroup's regions as holes (ray queues: path id = HOLE)
     const f4 hole_b{0.0f, 0.0f, 0.0f, asf(HOLE)};
     for (uint32_t i = sh_append.region[0].cur + threadIdx.x; i < sh_append.region[0].end; i += blockDim.x) io.rq_shadow.b[i] = hole_b;
@@ -1768,13 +1743,13 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t cap_in,
-                            uint32_t* heads, uint32_t* occluded, uint32_t* n_valid, f4* radiance = nullptr)
+                            uint32_t* heads, uint32_t* occluded, f4* radiance = nullptr)
 {
     const size_t lds = trace_lds_bytes(tl);
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
     const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
-#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, occluded, n_valid, radiance)
+#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, occluded, radiance)
     if (tl.lds_scene && !spill) PT_LAUNCH((k_any<true, MODE, false>));
     else if (tl.lds_scene) PT_LAUNCH((k_any<true, MODE, true>));
     else if (!spill) PT_LAUNCH((k_any<false, MODE, false>));
@@ -1802,8 +1777,6 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     out.cap_term = wb.cap_slots_term;
     out.class_mask = wb.class_mask | (1u << Q_TERMINAL);
     out.overflow = &row->overflow;
-    out.n_light_hit = nullptr;
-    out.n_valid = &row->valid_closest;
     if (b == 0u)
     {
         out.eye = f3{cam.eye[0], cam.eye[1], cam.eye[2]};
@@ -1829,7 +1802,7 @@ void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
 {
     Counters* row = wb.counters + b;
     launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, wb.cap_slots, row_heads(wb, b, HEADS_SHADOW),
-                                reinterpret_cast<uint32_t*>(wb.st.rec), &row->valid_shadow, wb.st.radiance);
+                                reinterpret_cast<uint32_t*>(wb.st.rec), wb.st.radiance);
 }
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -1837,8 +1810,6 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     ClosestOut out{};
     out.hits = wb.lchain_hit;
     out.n_shade = nullptr;
-    out.n_light_hit = &row->n_lchain_hit;
-    out.n_valid = &row->valid_lchain;
     out.world_root = tl.scene.world_root;
     out.occl = wb.st.occl;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, wb.cap_slots, row_heads(wb, b, HEADS_LCHAIN), out);
@@ -1866,6 +1837,7 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.cap_slots_term = wb.cap_slots_term;
     io.cap_slots_shade = wb.cap_slots_shade;
     io.ctr = wb.counters + b;
+    io.lchain_heads = row_heads(wb, b, HEADS_LCHAIN);
     io.ctr_next = wb.counters + b + 1u;
     switch (qclass)
     {
@@ -1910,7 +1882,7 @@ void launch_trace_rays_closest(hipStream_t s, const TraceLaunch& tl, uint32_t ro
 }
 void launch_trace_rays_any(hipStream_t s, const TraceLaunch& tl, uint32_t root, RayQueue rq, uint32_t n, uint32_t* n_and_heads, uint32_t* occluded)
 {
-    launch_any_impl<ANY_HOOK>(s, tl, root, rq, n_and_heads, n, n_and_heads + 32, occluded, nullptr);
+    launch_any_impl<ANY_HOOK>(s, tl, root, rq, n_and_heads, n, n_and_heads + 32, occluded);
 }
 void launch_sobol_probe(hipStream_t s, uint32_t n_points, uint32_t n, const uint32_t* index, const uint32_t* seed, float* out_xy)
 {

@@ -99,12 +99,9 @@ struct Counters
     uint32_t spare0;
     uint32_t n_lchain;       // BSDF-sampled NEE rays (lights TLAS closest hit, then world any hit)
     uint32_t spare1;
-    uint32_t valid_lchain;   // BSDF-sampled NEE rays actually traced (queue counters count slots, holes included)
-    uint32_t n_lchain_hit;   // of those, how many hit a light (= any-hit casts of integrator.rs:103)
+    uint32_t spare2, spare3;
     uint32_t n_shade[Q_COUNT];
-    uint32_t valid_closest;  // world closest-hit rays actually traced
-    uint32_t valid_shadow;   // explicit-light shadow rays actually traced
-    uint32_t culled_lchain;  // BSDF-sampled NEE rays that miss the lights TLAS's root box: cast (integrator.rs:100) and answered in the shading pass
+    uint32_t spare4, spare5, spare6; // (exact ray tallies live in the claim-cursor lines: HEAD_TALLY*)
 };
 static_assert(sizeof(Counters) == 64, "");
 
@@ -216,6 +213,10 @@ struct RayQueue
 // moves on (steals) when its home runs dry.  Zeroed with the counters once per batch.
 enum : uint32_t { kQueueHeads = 64u, kHeadStrideWords = 32u, kHeadWordsPerQueue = kQueueHeads * kHeadStrideWords };
 enum : uint32_t { HEADS_CLOSEST = 0, HEADS_SHADOW = 1, HEADS_LCHAIN = 2, HEADS_PER_ROW = 3 };
+// words of a cursor's cache line: the cursor itself, then exact tallies that the waves whose home partition this is add to
+// (rays actually traced — the queue counters count slots, holes included —, BSDF-sampled NEE rays that hit a light, BSDF-sampled NEE
+// rays the shading pass culled against the lights' root box)
+enum : uint32_t { HEAD_CURSOR = 0, HEAD_TALLY0 = 1, HEAD_TALLY1 = 2, HEAD_TALLY2 = 3 };
 // every queue is allocated with this many slots past its capacity: a producer that finds the queue full diverts its writes there
 // (see wave_reserve) instead of past the end
 enum : uint32_t { kQueueDumpSlots = 8192u };

@@ -209,6 +209,8 @@ typedef struct pt_stats
     uint32_t lds_scene;              /* 1 if traversal reads the BVH from LDS */
     uint32_t stack_entries;
     uint64_t state_bytes;            /* wavefront state + queues resident in HBM */
+    uint64_t rays_light_closest_traced; /* of rays_light_closest, those that went through the lights TLAS (the others miss its root box:
+                                        the shading pass answers them with that one slab test, tlas.rs:68-74) */
 } pt_stats;
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 /* counter rows of the LAST wavefront batch, 16 words per bounce (diagnostic): [0] closest-queue slots, [2] shadow-queue slots,

@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("launches_trace_closest", C.c_uint64), ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double),
                 ("ms_trace_light", C.c_double), ("ms_shade", C.c_double), ("ms_generate", C.c_double), ("ms_accumulate", C.c_double),
                 ("ms_total", C.c_double), ("scene_bytes", C.c_uint64), ("lds_scene", C.c_uint32), ("stack_entries", C.c_uint32),
-                ("state_bytes", C.c_uint64)]
+                ("state_bytes", C.c_uint64), ("rays_light_closest_traced", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -55,14 +55,40 @@ struct pt_ctx
     bool dev_ready = false;
     int device = 0;
     int n_cus = 256;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side_stream = nullptr;            // the (tiny) BSDF-sampled NEE launch runs beside the shadow-ray launch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr; // `stream` is what pipeline 0 launches on (the caller's, after pt_set_stream)
+    hipEvent_t ev_start = nullptr;                      // render start on `stream`: what the other pipelines wait for
+
+    // One wavefront pipeline: the state of ONE batch in flight and the streams it is launched on.  Batches are independent until they
+    // add their samples to the frame, so consecutive batches alternate between pipelines: the tail of one batch's launches (a few
+    // waves finishing the longest rays) overlaps the body of the other's instead of leaving the device idle.
+    struct Pipe
+    {
+        hipStream_t own_stream = nullptr, side_stream = nullptr; // side: the (tiny) BSDF-sampled NEE launch runs beside the shadow-ray launch
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr; // ev_done: this pipeline's last batch has been accumulated
+        size_t cap_paths = 0, cap_slots = 0, cap_slots_term = 0;
+        uint32_t cap_rows = 0;
+        std::vector<DevBuf> pool;
+        WavefrontBuffers wb{};
+        Counters* h_counters = nullptr; // pinned
+        uint32_t* h_heads = nullptr;    // pinned mirror of the claim-cursor lines (they carry the exact ray tallies)
+        struct Ev { hipEvent_t a, b; int cat; };
+        std::vector<Ev> ev_pool;
+        size_t ev_used = 0;
+        uint32_t slack_cfg = 0;         // pt_config.queue_slack the pool was sized with
+        uint32_t pixels_cfg = 0;        // local pixel count the pool was sized with (first-hit buffers)
+        size_t state_bytes = 0;
+        bool busy = false;              // a batch has been launched and not yet harvested
+        uint32_t busy_rows = 0;
+        uint64_t busy_paths = 0;
+    };
+    static constexpr int kMaxPipes = 4;
+    Pipe pipe[kMaxPipes];
+    hipStream_t pipe_stream(int i) const { return i == 0 ? stream : pipe[i].own_stream; }
 
     // scene residency
     bool scene_uploaded = false;
     DevBuf d_spill;
-    size_t spill_region_words = 0; // 8-byte words per traversal launch's spill area (d_spill holds two)
+    size_t spill_region_words = 0; // 8-byte words per traversal launch's spill area (d_spill holds two per pipeline)
     DevBuf d_blob, d_tri_shade, d_tri_pos, d_tri_orig, d_materials, d_lights, d_env;
     std::vector<f4> h_env;
     uint32_t env_w = 0, env_h = 0;
@@ -78,19 +104,9 @@ struct pt_ctx
     DevBuf d_accum, d_position, d_id;
     DevBuf d_input, d_velocity, d_output; // State::update textures (pt_frame)
 
-    // wavefront
-    size_t cap_paths = 0, cap_slots = 0, cap_slots_term = 0;
-    uint32_t cap_rows = 0;
-    std::vector<DevBuf> pool;
-    WavefrontBuffers wb{};
-    Counters* h_counters = nullptr; // pinned
-    uint32_t* h_heads = nullptr;    // pinned mirror of the claim-cursor lines (they carry the exact ray tallies)
-
     // stats
     pt_stats stats{};
-    struct Ev { hipEvent_t a, b; int cat; };
-    std::vector<Ev> ev_pool;
-    size_t ev_used = 0;
+    int last_pipe = 0; // pipeline whose counters pt_last_batch_counters reports
 };
 
 namespace {
@@ -163,13 +179,16 @@ int ensure_device(pt_ctx* c)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    for (int i = 0; i < pt_ctx::kMaxPipes; ++i)
     {
-        int lo = 0, hi = 0; // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHK(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, PT_SIDE_PRIORITY ? hi : lo));
+        pt_ctx::Pipe& pp = c->pipe[i];
+        if (i > 0) HIPCHK(c, hipStreamCreateWithFlags(&pp.own_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&pp.side_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&pp.ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&pp.ev_join, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&pp.ev_done, hipEventDisableTiming));
     }
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (!c->stream) c->stream = c->own_stream;
     c->dev_ready = true;
     return PT_OK;
@@ -234,7 +253,7 @@ int upload_scene(pt_ctx* c)
 #define PT_STACK_LDS_LEVELS 14
 #endif
     sv.stack_lds = std::min<uint32_t>(sv.stack_entries, c->cfg.stack_lds_levels ? c->cfg.stack_lds_levels : PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8 + (size_t)(t / 64) * 2048; }; // + binning stage
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8; };
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -245,11 +264,11 @@ int upload_scene(pt_ctx* c)
     sv.stack_spill = nullptr;
     if (sv.stack_entries > sv.stack_lds)
     {
-        // two regions: the BSDF-sampled NEE launch runs on the side stream BESIDE the shadow-ray launch (nee_launches), and the spill
-        // slots are indexed by lane only, so concurrent traversal kernels must not share them
+        // two regions per pipeline: the BSDF-sampled NEE launch runs on the side stream BESIDE the shadow-ray launch (nee_launches),
+        // pipelines run beside each other, and the spill slots are indexed by lane only, so concurrent traversal kernels must not share them
         const size_t lanes = (size_t)c->trace_blocks * threads;
         c->spill_region_words = (size_t)(sv.stack_entries - sv.stack_lds) * lanes;
-        if ((r = dev_alloc(c, c->d_spill, 2 * c->spill_region_words * 8))) return r;
+        if ((r = dev_alloc(c, c->d_spill, 2 * pt_ctx::kMaxPipes * c->spill_region_words * 8))) return r;
         sv.stack_spill = (uint64_t*)c->d_spill.p;
     }
 
@@ -262,11 +281,11 @@ int upload_scene(pt_ctx* c)
     return PT_OK;
 }
 
-TraceLaunch trace_launch(pt_ctx* c, bool side_stream = false)
+TraceLaunch trace_launch(pt_ctx* c, int pipe = 0, bool side_stream = false)
 {
     TraceLaunch tl;
     tl.scene = c->sv;
-    if (side_stream && tl.scene.stack_spill) tl.scene.stack_spill += c->spill_region_words;
+    if (tl.scene.stack_spill) tl.scene.stack_spill += (size_t)(2 * pipe + (side_stream ? 1 : 0)) * c->spill_region_words;
     tl.blob = c->d_blob.p;
     tl.lds_scene = c->lds_scene;
     tl.grid_blocks = c->trace_blocks;
@@ -292,16 +311,27 @@ int ensure_frame(pt_ctx* c)
     return PT_OK;
 }
 
-int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
+void free_pipe_pool(pt_ctx::Pipe& pp)
 {
-    const bool vstack_ok = !c->sv.has_volumes || c->wb.st.vstack != nullptr;
+    for (DevBuf& b : pp.pool) dev_free(b);
+    pp.pool.clear();
+    if (pp.h_counters) { (void)hipHostFree(pp.h_counters); pp.h_counters = nullptr; }
+    if (pp.h_heads) { (void)hipHostFree(pp.h_heads); pp.h_heads = nullptr; }
+    pp.cap_paths = 0;
+    pp.cap_rows = 0;
+    pp.wb = WavefrontBuffers{};
+}
+
+int ensure_wavefront(pt_ctx* c, int pipe, size_t n_paths, uint32_t rows)
+{
+    pt_ctx::Pipe& pp = c->pipe[pipe];
+    const bool vstack_ok = !c->sv.has_volumes || pp.wb.st.vstack != nullptr;
     bool queues_ok = true; // a scene edit may have introduced a material class the pool has no shade queue for
-    for (uint32_t q = 1; q < Q_COUNT; ++q) queues_ok = queues_ok && (!c->class_present[q] || ((c->wb.class_mask >> q) & 1u));
-    if (c->cap_paths >= n_paths && c->cap_rows >= rows && vstack_ok && queues_ok) return PT_OK;
-    for (DevBuf& b : c->pool) dev_free(b);
-    c->pool.clear();
-    if (c->h_counters) { (void)hipHostFree(c->h_counters); c->h_counters = nullptr; }
-    if (c->h_heads) { (void)hipHostFree(c->h_heads); c->h_heads = nullptr; }
+    for (uint32_t q = 1; q < Q_COUNT; ++q) queues_ok = queues_ok && (!c->class_present[q] || ((pp.wb.class_mask >> q) & 1u));
+    if (pp.cap_paths >= n_paths && pp.cap_rows >= rows && vstack_ok && queues_ok && pp.slack_cfg == c->cfg.queue_slack && pp.pixels_cfg == c->local_pixels) return PT_OK;
+    free_pipe_pool(pp);
+    pp.slack_cfg = c->cfg.queue_slack;
+    pp.pixels_cfg = c->local_pixels;
     n_paths = std::max<size_t>(n_paths, 64);
     // Queues hold slots, not entries: every producer may leave the tail of its last region as holes.  A traversal wave reserves
     // max(64, n_in / (8 * waves)) slots at a time and a shading workgroup max(256, n_in / (8 * workgroups)) (region_size in
@@ -316,20 +346,20 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     // test mode: the surface shade queues are SMALLER than the batch (the ray queues cannot be: the camera rays of a batch fill one)
     const size_t n_slots_shade = (c->cfg.queue_slack & 0x80000000u) ? std::max<size_t>(n_paths * frac / 1024, 64) : n_slots;
     if (n_slots_term + kQueueDumpSlots >= (1ull << 32)) return fail(c, PT_ERR_LIMIT, "batch too large for 32-bit queue slots");
-    c->cap_slots = n_slots;
-    c->cap_slots_term = n_slots_term;
+    pp.cap_slots = n_slots;
+    pp.cap_slots_term = n_slots_term;
     size_t total = 0;
     auto take = [&](size_t bytes, void** out) -> int {
         DevBuf b;
         int r = dev_alloc(c, b, bytes);
         if (r) return r;
-        c->pool.push_back(b);
+        pp.pool.push_back(b);
         *out = b.p;
         total += b.bytes;
         return PT_OK;
     };
     int r;
-    WavefrontBuffers& w = c->wb;
+    WavefrontBuffers& w = pp.wb;
     const size_t qs = n_slots + kQueueDumpSlots, qs_term = n_slots_term + kQueueDumpSlots; // allocated slots incl. the dump area
 #define TAKE(ptr, bytes)                                  \
     if ((r = take((bytes), (void**)&(ptr)))) return r;
@@ -338,8 +368,9 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     TAKE(w.st.occl, n_paths);
     if (c->sv.has_volumes) { TAKE(w.st.vstack, n_paths * 4); }
     else w.st.vstack = nullptr;
-    TAKE(w.st.first_pos, n_paths * 16);
-    TAKE(w.st.first_id, n_paths * 4);
+    // first-hit position / id: only the batch's last sample / last two samples are ever read (RenderParams::keep_*_from)
+    TAKE(w.st.first_pos, (size_t)std::max<uint32_t>(c->local_pixels, 64) * 16);
+    TAKE(w.st.first_id, (size_t)std::max<uint32_t>(c->local_pixels, 64) * 2 * 4);
     for (int k = 0; k < 2; ++k)
     {
         TAKE(w.rq[k].a, qs * 16);
@@ -371,51 +402,55 @@ int ensure_wavefront(pt_ctx* c, size_t n_paths, uint32_t rows)
     w.cap_slots = (uint32_t)n_slots;
     w.cap_slots_shade = (uint32_t)n_slots_shade;
     w.cap_slots_term = (uint32_t)n_slots_term;
-    HIPCHK(c, hipHostMalloc((void**)&c->h_counters, (size_t)rows * sizeof(Counters), hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipHostMallocDefault));
-    c->cap_paths = n_paths;
-    c->cap_rows = rows;
-    c->stats.state_bytes = total;
+    HIPCHK(c, hipHostMalloc((void**)&pp.h_counters, (size_t)rows * sizeof(Counters), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&pp.h_heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipHostMallocDefault));
+    pp.cap_paths = n_paths;
+    pp.cap_rows = rows;
+    pp.state_bytes = total;
+    c->stats.state_bytes = 0;
+    for (const pt_ctx::Pipe& q : c->pipe) c->stats.state_bytes += q.cap_paths ? q.state_bytes : 0;
     return PT_OK;
 }
 
 struct Timer
 {
     pt_ctx* c;
+    pt_ctx::Pipe& pp;
+    hipStream_t stream;
     int cat;
     bool on;
     size_t slot = 0;
-    Timer(pt_ctx* c_, int cat_)
-        : c(c_), cat(cat_), on((c_->cfg.flags & PT_FLAG_TIMING_ALL) != 0 || (cat_ == T_WORLD && (c_->cfg.flags & PT_FLAG_TIMING) != 0))
+    Timer(pt_ctx* c_, pt_ctx::Pipe& pp_, hipStream_t s_, int cat_)
+        : c(c_), pp(pp_), stream(s_), cat(cat_), on((c_->cfg.flags & PT_FLAG_TIMING_ALL) != 0 || (cat_ == T_WORLD && (c_->cfg.flags & PT_FLAG_TIMING) != 0))
     {
         if (!on) return;
-        if (c->ev_used == c->ev_pool.size())
+        if (pp.ev_used == pp.ev_pool.size())
         {
-            pt_ctx::Ev e;
+            pt_ctx::Pipe::Ev e;
             (void)hipEventCreate(&e.a);
             (void)hipEventCreate(&e.b);
-            c->ev_pool.push_back(e);
+            pp.ev_pool.push_back(e);
         }
-        slot = c->ev_used++;
-        c->ev_pool[slot].cat = cat;
-        (void)hipEventRecord(c->ev_pool[slot].a, c->stream);
+        slot = pp.ev_used++;
+        pp.ev_pool[slot].cat = cat;
+        (void)hipEventRecord(pp.ev_pool[slot].a, stream);
     }
     ~Timer()
     {
-        if (on) (void)hipEventRecord(c->ev_pool[slot].b, c->stream);
+        if (on) (void)hipEventRecord(pp.ev_pool[slot].b, stream);
     }
 };
 
-void harvest_events(pt_ctx* c)
+void harvest_events(pt_ctx* c, pt_ctx::Pipe& pp)
 {
     double ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < c->ev_used; ++i)
+    for (size_t i = 0; i < pp.ev_used; ++i)
     {
         float t = 0;
-        if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) ms[c->ev_pool[i].cat] += t;
-        if (c->ev_pool[i].cat == T_WORLD) c->stats.launches_trace_closest++;
+        if (hipEventElapsedTime(&t, pp.ev_pool[i].a, pp.ev_pool[i].b) == hipSuccess) ms[pp.ev_pool[i].cat] += t;
+        if (pp.ev_pool[i].cat == T_WORLD) c->stats.launches_trace_closest++;
     }
-    c->ev_used = 0;
+    pp.ev_used = 0;
     c->stats.ms_generate += ms[T_GEN];
     c->stats.ms_trace_closest += ms[T_WORLD];
     c->stats.ms_trace_any += ms[T_ANY];
@@ -424,9 +459,47 @@ void harvest_events(pt_ctx* c)
     c->stats.ms_accumulate += ms[T_ACCUM];
 }
 
-// one wavefront batch: samples [first, first+count) of every local pixel
-int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples = false)
+// what a launched batch leaves behind: overflow flags and exact ray tallies.  Blocks until the pipeline's stream is idle.
+int harvest_batch(pt_ctx* c, int pipe)
 {
+    pt_ctx::Pipe& pp = c->pipe[pipe];
+    if (!pp.busy) return PT_OK;
+    pp.busy = false;
+    HIPCHK(c, hipStreamSynchronize(c->pipe_stream(pipe)));
+    HIPCHK(c, hipGetLastError());
+    const uint32_t rows = pp.busy_rows;
+    for (uint32_t r = 0; r < rows; ++r)
+        // a producer that found a queue full has diverted its entries to the queue's dump area (nothing was written out of bounds)
+        // and raised this flag: the batch's results are incomplete
+        if (pp.h_counters[r].overflow) return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
+    // exact tallies live beside the claim cursors, one per cursor line (64 addresses per queue instead of one: a launch of a few
+    // thousand waves that each add to ONE word spends ~50 us on that alone)
+    for (uint32_t r = 0; r < rows; ++r)
+    {
+        const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
+        for (uint32_t g = 0; g < kQueueHeads; ++g)
+        {
+            const uint32_t* cl = hrow + HEADS_CLOSEST * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* sh = hrow + HEADS_SHADOW * kHeadWordsPerQueue + g * kHeadStrideWords;
+            const uint32_t* lc = hrow + HEADS_LCHAIN * kHeadWordsPerQueue + g * kHeadStrideWords;
+            c->stats.rays_closest += cl[HEAD_TALLY0];
+            c->stats.rays_any += (uint64_t)sh[HEAD_TALLY0] + lc[HEAD_TALLY1];
+            c->stats.rays_light_closest_traced += lc[HEAD_TALLY0];
+            c->stats.rays_light_closest += (uint64_t)lc[HEAD_TALLY0] + lc[HEAD_TALLY2]; // casts of integrator.rs:100, whoever answered them
+        }
+    }
+    c->stats.paths += pp.busy_paths;
+    c->last_pipe = pipe;
+    harvest_events(c, pp);
+    return PT_OK;
+}
+
+// one wavefront batch: samples [first, first+count) of every local pixel, launched on pipeline `pipe` (nothing here waits for the
+// device except the emptiness probes of very long bounce budgets).  `after`: event the batch's accumulation must wait for (the
+// previous batch's accumulation: samples are added to the frame in sample order), or null.
+int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples, hipEvent_t after)
+{
+    pt_ctx::Pipe& pp = c->pipe[pipe];
     const pt_config& g = c->cfg;
     RenderParams rp{};
     rp.width = g.width;
@@ -449,9 +522,9 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     rp.div_width = fastdiv_make(rp.width);
     rp.div_strip_rows = fastdiv_make(rp.strip_rows);
     const uint32_t rows = g.max_bounces + 2;
-    hipStream_t s = c->stream;
-    const WavefrontBuffers& wb = c->wb;
-    const TraceLaunch tl = trace_launch(c), tl_side = trace_launch(c, true);
+    hipStream_t s = c->pipe_stream(pipe);
+    const WavefrontBuffers& wb = pp.wb;
+    const TraceLaunch tl = trace_launch(c, pipe, false), tl_side = trace_launch(c, pipe, true);
     CameraView cam{};
     std::memcpy(cam.ray_matrix, c->scene.camera.ray_matrix, 64);
     cam.eye[0] = c->scene.camera.matrix.t.x;
@@ -460,46 +533,39 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     EnvView env{};
     if (c->env_w)
     {
-        if (!c->env_uploaded)
-        {
-            int er = dev_alloc(c, c->d_env, c->h_env.size() * sizeof(f4));
-            if (er) return er;
-            HIPCHK(c, hipMemcpyAsync(c->d_env.p, c->h_env.data(), c->h_env.size() * sizeof(f4), hipMemcpyHostToDevice, c->stream));
-            c->env_uploaded = true;
-        }
-        env.data = (const f4*)c->d_env.p;
+        env.data = (const f4*)c->d_env.p; // uploaded by the caller (ensure_environment)
         env.w = c->env_w;
         env.h = c->env_h;
     }
 
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
     HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, s));
-    { Timer t(c, T_GEN); launch_generate(s, rp, cam, wb); }
+    { Timer t(c, pp, s, T_GEN); launch_generate(s, rp, cam, wb); }
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU);
     const bool nee = g.enable_nee != 0;
     // The BSDF-sampled NEE launch of a bounce has almost nothing to do since shading answers the rays that miss the lights' root box
-    // (it is all launch latency and tail), and nothing before the next SHADING pass reads its results (the closest-hit kernel leaves
-    // paths that cast such a ray to the terminal queue).  It runs on a high-priority side stream beside the shadow-ray launch and the
-    // next closest-hit launch; the main stream waits for it only before it shades.
+    // (it is all launch latency and tail).  It runs on a side stream beside the shadow-ray launch; the main stream waits for it before
+    // the next closest-hit launch (waiting only before the next SHADING pass, the first reader of its results, was measured: +2 ms per
+    // frame, the two traversal kernels fight for wave slots).
     int nee_err = PT_OK;
     bool side_busy = false;
     auto nee_launches = [&](uint32_t row) {
         const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
         if (timing_all)
         {
-            { Timer t(c, T_ANY); launch_trace_shadow(s, tl, wb, row); }
-            { Timer t(c, T_LIGHT); launch_trace_lchain(s, tl, wb, row); }
+            { Timer t(c, pp, s, T_ANY); launch_trace_shadow(s, tl, wb, row); }
+            { Timer t(c, pp, s, T_LIGHT); launch_trace_lchain(s, tl, wb, row); }
             return;
         }
-        if (hipEventRecord(c->ev_fork, s) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
-        launch_trace_lchain(c->side_stream, tl_side, wb, row);
-        if (hipEventRecord(c->ev_join, c->side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
+        if (hipEventRecord(pp.ev_fork, s) != hipSuccess || hipStreamWaitEvent(pp.side_stream, pp.ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
+        launch_trace_lchain(pp.side_stream, tl_side, wb, row);
+        if (hipEventRecord(pp.ev_join, pp.side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
         side_busy = true;
         launch_trace_shadow(s, tl, wb, row);
     };
     auto join_side = [&]() {
         if (!side_busy) return;
-        if (hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
+        if (hipStreamWaitEvent(s, pp.ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
         side_busy = false;
     };
     uint32_t last_row = rows - 1;
@@ -512,16 +578,16 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
 #if !PT_JOIN_LATE
         join_side();
 #endif
-        { Timer t(c, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
+        { Timer t(c, pp, s, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
         join_side();
         for (uint32_t q = 0; q < Q_COUNT; ++q)
-            if (c->class_present[q]) { Timer t(c, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam, env); }
+            if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam, env); }
         // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
         if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
         {
-            HIPCHK(c, hipMemcpyAsync(c->h_counters + b + 1, wb.counters + b + 1, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(pp.h_counters + b + 1, wb.counters + b + 1, sizeof(Counters), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
-            const Counters& nx = c->h_counters[b + 1];
+            const Counters& nx = pp.h_counters[b + 1];
             if (nx.n_closest == 0) { last_row = b + 1; break; }
         }
     }
@@ -531,9 +597,10 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     {
         nee_launches(last_row - 1);
         join_side();
-        { Timer t(c, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
+        { Timer t(c, pp, s, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
     }
     if (nee_err) return fail(c, PT_ERR_HIP, "stream fork/join failed");
+    if (after && hipStreamWaitEvent(s, after, 0) != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamWaitEvent");
     if (samples_out)
     {
         launch_store_samples(s, rp, wb, samples_out);
@@ -542,38 +609,35 @@ int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_posit
     }
     else
     {
-        Timer t(c, T_ACCUM);
+        Timer t(c, pp, s, T_ACCUM);
         launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_heads, wb.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipGetLastError());
-    for (uint32_t r = 0; r < rows; ++r)
-    {
-        const Counters& k = c->h_counters[r];
-        // a producer that found a queue full has diverted its entries to the queue's dump area (nothing was written out of bounds)
-        // and raised this flag: the batch's results are incomplete
-        if (k.overflow) return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
-    }
-    // exact tallies live beside the claim cursors, one per cursor line (64 addresses per queue instead of one: a launch of a few
-    // thousand waves that each add to ONE word spends ~50 us on that alone)
-    for (uint32_t r = 0; r < rows; ++r)
-    {
-        const uint32_t* hrow = c->h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
-        for (uint32_t g = 0; g < kQueueHeads; ++g)
-        {
-            const uint32_t* cl = hrow + HEADS_CLOSEST * kHeadWordsPerQueue + g * kHeadStrideWords;
-            const uint32_t* sh = hrow + HEADS_SHADOW * kHeadWordsPerQueue + g * kHeadStrideWords;
-            const uint32_t* lc = hrow + HEADS_LCHAIN * kHeadWordsPerQueue + g * kHeadStrideWords;
-            c->stats.rays_closest += cl[HEAD_TALLY0];
-            c->stats.rays_any += (uint64_t)sh[HEAD_TALLY0] + lc[HEAD_TALLY1];
-            c->stats.rays_light_closest += (uint64_t)lc[HEAD_TALLY0] + lc[HEAD_TALLY2]; // casts of integrator.rs:100, whoever answered them
-        }
-    }
-    c->stats.paths += rp.n_paths;
-    harvest_events(c);
+    HIPCHK(c, hipEventRecord(pp.ev_done, s));
+    HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
+    pp.busy = true;
+    pp.busy_rows = rows;
+    pp.busy_paths = rp.n_paths;
     return PT_OK;
+}
+
+int ensure_environment(pt_ctx* c)
+{
+    if (!c->env_w || c->env_uploaded) return PT_OK;
+    int er = dev_alloc(c, c->d_env, c->h_env.size() * sizeof(f4));
+    if (er) return er;
+    HIPCHK(c, hipMemcpy(c->d_env.p, c->h_env.data(), c->h_env.size() * sizeof(f4), hipMemcpyHostToDevice));
+    c->env_uploaded = true;
+    return PT_OK;
+}
+
+// one batch on pipeline 0, start to finish
+int run_batch(pt_ctx* c, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples = false)
+{
+    int r;
+    if ((r = ensure_environment(c))) return r;
+    if ((r = launch_batch(c, 0, first_sample, count, write_position, samples_out, aux_with_samples, nullptr))) return r;
+    return harvest_batch(c, 0);
 }
 
 int precheck(pt_ctx* c)
@@ -591,41 +655,85 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     if (n_samples == 0 || c->local_pixels == 0) return PT_OK;
     if ((r = upload_scene(c))) return r;
     if ((r = ensure_frame(c))) return r;
-    // Auto batch: as many samples per pixel resident as HBM allows (fewer, larger launches: the late bounces of a small batch
-    // cannot fill 256 CUs).  ~390 B of wavefront state per path; path ids are 29-bit (queue slot indices use all 32).
+    if ((r = ensure_environment(c))) return r;
+    // Batches: by default the whole request stays resident when HBM allows; otherwise (or with pt_config.batch_spp) it is cut into
+    // equal batches that alternate between `pipelines` wavefront pipelines on their own HIP streams, so that one batch's launch
+    // tails overlap the other's launches.  ~PT_BYTES_PER_PATH of wavefront state per path; path ids are 29-bit.
+    const uint32_t want_pipes = samples_out ? 1u : std::min<uint32_t>(c->cfg.pipelines ? c->cfg.pipelines : 2u, (uint32_t)pt_ctx::kMaxPipes);
     size_t max_paths = (size_t)96 << 20;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
         {
             size_t held = 0;
-            for (const DevBuf& b : c->pool) held += b.bytes;
-            max_paths = (size_t)((double)(free_b + held) * 0.75 / 390.0);
+            for (const pt_ctx::Pipe& pp : c->pipe)
+                for (const DevBuf& b : pp.pool) held += b.bytes;
+            max_paths = (size_t)((double)(free_b + held) * 0.75 / 410.0);
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }
     uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
     batch = std::min(batch, n_samples);
-    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
-    const uint32_t n_batches = (n_samples + batch - 1) / batch;
+    uint32_t n_batches = (n_samples + batch - 1) / batch;
+    // A request that fits at once but is small (one rank's share of a sharded frame) is still cut in two: its launches are short
+    // enough that their tails matter, and two half batches on two pipelines hide them (measured on a 1/8 share of the 1080p x 256 spp
+    // frame: -8 %; on the whole frame: +1 %, hence the threshold).
+    if (!c->cfg.batch_spp && n_batches == 1 && want_pipes > 1 && n_samples >= 2 && (uint64_t)n_samples * c->local_pixels <= ((uint64_t)160 << 20))
+    {
+        batch = (n_samples + 1) / 2;
+        n_batches = 2;
+    }
+    uint32_t n_pipes = std::min(want_pipes, n_batches);
+    if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * c->local_pixels * n_pipes > max_paths)
+    {
+        // the request does not fit at once: the pipelines share the memory
+        batch = (uint32_t)std::max<size_t>(1, max_paths / n_pipes / c->local_pixels);
+        n_batches = (n_samples + batch - 1) / batch;
+    }
     batch = (n_samples + n_batches - 1) / n_batches;
-    if ((r = ensure_wavefront(c, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;
+    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
+    // pipelines this call does not use give their memory back
+    for (int i = (int)n_pipes; i < pt_ctx::kMaxPipes; ++i)
+        if (!c->pipe[i].busy && c->pipe[i].cap_paths) free_pipe_pool(c->pipe[i]);
+    for (uint32_t i = 0; i < n_pipes; ++i)
+        if ((r = ensure_wavefront(c, (int)i, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;
     DevBuf d_samples;
     if (samples_out && (r = dev_alloc(c, d_samples, (size_t)batch * c->local_pixels * 16))) return r;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t done = 0; done < n_samples; done += batch)
+    // the other pipelines start after whatever the caller queued on pipeline 0's stream (accumulation resets, uploads)
+    if (n_pipes > 1)
     {
+        HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
+        for (uint32_t i = 1; i < n_pipes; ++i) HIPCHK(c, hipStreamWaitEvent(c->pipe_stream((int)i), c->ev_start, 0));
+    }
+    hipEvent_t prev_done = nullptr;
+    uint32_t k = 0;
+    int err = PT_OK;
+    for (uint32_t done = 0; done < n_samples && !err; done += batch, ++k)
+    {
+        const int pi = (int)(k % n_pipes);
         const uint32_t cnt = std::min(batch, n_samples - done);
-        r = run_batch(c, first_sample + done, cnt, done + cnt == n_samples, samples_out ? (f4*)d_samples.p : nullptr);
-        if (r) { dev_free(d_samples); return r; }
+        if ((err = harvest_batch(c, pi))) break; // the pipeline's previous batch must be done before its buffers are reused
+        if ((err = launch_batch(c, pi, first_sample + done, cnt, done + cnt == n_samples, samples_out ? (f4*)d_samples.p : nullptr, false, prev_done))) break;
+        prev_done = c->pipe[pi].ev_done;
         if (samples_out)
         {
+            if ((err = harvest_batch(c, pi))) break;
             hipError_t e = hipMemcpy(samples_out + (size_t)done * c->local_pixels * 4, d_samples.p, (size_t)cnt * c->local_pixels * 16, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { dev_free(d_samples); return fail(c, PT_ERR_HIP, hipGetErrorString(e)); }
+            if (e != hipSuccess) err = fail(c, PT_ERR_HIP, hipGetErrorString(e));
         }
     }
-    c->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t i = 0; i < n_pipes; ++i)
+    {
+        const int hr = harvest_batch(c, (int)i);
+        if (hr && !err) err = hr;
+    }
+    // whatever the caller queues next on pipeline 0's stream comes after the last accumulation (harvest_batch has waited for every
+    // pipeline, so this is already true for the host; the event keeps stream order explicit for callers that share the stream)
+    if (!err && prev_done && n_pipes > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, prev_done, 0));
     dev_free(d_samples);
+    if (err) return err;
+    c->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
 
@@ -653,16 +761,22 @@ void pt_destroy(pt_ctx* c)
     if (c->dev_ready)
     {
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf& b : c->pool) dev_free(b);
+        for (int i = 0; i < pt_ctx::kMaxPipes; ++i)
+        {
+            pt_ctx::Pipe& pp = c->pipe[i];
+            (void)hipStreamSynchronize(c->pipe_stream(i));
+            free_pipe_pool(pp);
+            for (auto& e : pp.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+            if (pp.own_stream) (void)hipStreamDestroy(pp.own_stream);
+            if (pp.side_stream) (void)hipStreamDestroy(pp.side_stream);
+            if (pp.ev_fork) (void)hipEventDestroy(pp.ev_fork);
+            if (pp.ev_join) (void)hipEventDestroy(pp.ev_join);
+            if (pp.ev_done) (void)hipEventDestroy(pp.ev_done);
+        }
         DevBuf* bufs[] = {&c->d_input, &c->d_velocity, &c->d_output, &c->d_blob, &c->d_tri_shade, &c->d_tri_pos, &c->d_tri_orig, &c->d_materials, &c->d_lights, &c->d_env, &c->d_spill, &c->d_accum, &c->d_position, &c->d_id};
         for (DevBuf* b : bufs) dev_free(*b);
-        if (c->h_counters) (void)hipHostFree(c->h_counters);
-        if (c->h_heads) (void)hipHostFree(c->h_heads);
-        for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-        if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     }
     delete c;
 }
@@ -678,7 +792,6 @@ int pt_set_config(pt_ctx* c, const pt_config* cfg)
     const pt_config old = c->cfg;
     int r = normalise_config(c, cfg);
     if (r) return r;
-    if (c->cfg.queue_slack != old.queue_slack) c->cap_paths = 0;             // the wavefront pool is sized with it
     if (c->cfg.stack_lds_levels != old.stack_lds_levels || ((c->cfg.flags ^ old.flags) & PT_FLAG_NO_LDS_SCENE)) c->scene_uploaded = false;
     if (c->dev_ready && cfg->device != old_dev && cfg->device >= 0) return fail(c, PT_ERR_STATE, "device cannot change after first use");
     if (c->local_pixels != old_px)
@@ -935,7 +1048,7 @@ int pt_frame(pt_ctx* c, uint32_t frame_index, const float* last_inv_projection, 
     const size_t px = c->local_pixels;
     if ((r = dev_alloc(c, c->d_input, px * 16)) || (r = dev_alloc(c, c->d_velocity, px * 8)) || (r = dev_alloc(c, c->d_output, px * 16))) return r;
     if (id) HIPCHK(c, hipMemcpyAsync(c->d_id.p, id, px * 4, hipMemcpyHostToDevice, c->stream));
-    if ((r = ensure_wavefront(c, px, c->cfg.max_bounces + 2))) return r;
+    if ((r = ensure_wavefront(c, 0, px, c->cfg.max_bounces + 2))) return r;
     if ((r = run_batch(c, frame_index, 1, true, (f4*)c->d_input.p, true))) return r;   // main.rs:181-207, one sample per pixel
     hipStream_t s = c->stream;
     const int w = (int)c->cfg.width, h = (int)c->cfg.height;
@@ -1330,15 +1443,16 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
 int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows)
 {
     if (!c || !rows16 || !n_rows) return PT_ERR_ARG;
-    if (!c->h_counters || !c->h_heads) return PT_ERR_STATE;
+    const pt_ctx::Pipe& pp = c->pipe[c->last_pipe];
+    if (!pp.h_counters || !pp.h_heads) return PT_ERR_STATE;
     const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
-    std::memcpy(rows16, c->h_counters, (size_t)rows * sizeof(Counters));
+    std::memcpy(rows16, pp.h_counters, (size_t)rows * sizeof(Counters));
     for (uint32_t r = 0; r < rows; ++r)
     {
         uint32_t* o = rows16 + 16 * r;
         o[1] = o[3] = o[5] = 0;
         o[6] = o[7] = o[13] = o[14] = o[15] = 0;
-        const uint32_t* hrow = c->h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
+        const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue;
         for (uint32_t g = 0; g < kQueueHeads; ++g)
         {
             const uint32_t* cl = hrow + HEADS_CLOSEST * kHeadWordsPerQueue + g * kHeadStrideWords;

@@ -37,12 +37,6 @@ namespace {
 #ifndef PT_CHUNK_DIV
 #define PT_CHUNK_DIV 4
 #endif
-#ifndef PT_TALLY
-#define PT_TALLY 1
-#endif
-#ifndef PT_REGION_MIN
-#define PT_REGION_MIN 64
-#endif
 constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
 constexpr int kStepsAny = PT_STEPS_ANY;
 constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
@@ -192,8 +186,11 @@ __device__ __forceinline__ void add_tally(uint32_t* heads, uint32_t per_lane, ui
 // entry or even wave by wave: a producer (a traversal wave, a shading workgroup) RESERVES a private region of the output
 // queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
 // when the producer exits is filled with HOLE markers that consumers skip (they come in runs, so skipping them costs a load per
-// 64); the queue's counter therefore counts slots, not entries.  Region size = slots_in / (producers * 8), clamped to [64, 8192],
-// with only the producers that actually take part counted: holes stay below ~1/16 of a large queue and a small launch stays small.
+// 64); the queue's counter therefore counts slots, not entries.  Region size = slots_in / (producers * 16), clamped to [64, 8192],
+// with only the producers that actually take part counted: holes stay below ~1/32 of a large queue and a small launch stays small
+// (same-box sweep of the divisor: 2 and 4 cost 2-5 ms per frame — holes are not free, a hole is an idle lane until the next refill —,
+// 8, 16 and 32 are within noise of each other; regions shared by the four waves of a workgroup through an LDS cursor cut the tail
+// atomics fourfold but their per-retirement LDS atomic cost 2 ms per frame).
 //
 // Capacity: a reservation that would pass the queue's capacity is diverted to the queue's dump area (kQueueDumpSlots slots past the
 // capacity, shared by everybody who overflows) and raises the batch's overflow flag: nothing is ever stored out of bounds, the
@@ -204,7 +201,7 @@ struct Region { uint32_t cur, end; };
 // `least`: the most one reservation has to take in one go (64 for a wave, 256 for a workgroup)
 __device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers, uint32_t least)
 {
-    uint32_t r = n_in / (max(producers, 1u) * 8u);
+    uint32_t r = n_in / (max(producers, 1u) * 16u);
     r = r < least ? least : (r > kQueueDumpSlots ? (uint32_t)kQueueDumpSlots : r);
     return (r + 63u) & ~63u;
 }
@@ -534,7 +531,7 @@ struct Stack8<true>
 
 // ------------------------------------------------------------------------------------------------ closest hit
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                                   const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                                   uint32_t* __restrict__ heads, const ClosestOut out)
 {
@@ -563,7 +560,7 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
     Region bin_region[Q_COUNT];
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
-    const uint32_t rsize = region_size(plan.n, plan.blocks * (blockDim.x >> 6), (uint32_t)PT_REGION_MIN);
+    const uint32_t rsize = region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
 
     for (;;)
     {
@@ -588,21 +585,21 @@ __global__ void __launch_bounds__(256) k_closest(const SceneView sv, const uint4
                         if (pending) out.occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
                         if (missed)
                         {
-                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
+                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
                             if (ray_idx >= out.keep_pos_from)
                             {
                                 const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out.first_pos[ray_idx] = f4{far.x, far.y, far.z, 1e5f};
+                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
                             }
                         }
                         else if (pending && bid == MISS_ID)
                         {
                             // environment map present: the terminal pass shades the miss; defaults of integrator.rs:156-157 still apply
-                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx] = 255u;
+                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
                             if (ray_idx >= out.keep_pos_from)
                             {
                                 const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out.first_pos[ray_idx] = f4{far.x, far.y, far.z, 1e5f};
+                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
                             }
                         }
                         qm = __ballot(pending && !missed);
@@ -1260,9 +1257,9 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
                     if (pid >= rp.keep_pos_from)
                     {
                         const f3 p = fma3(xyz(rb), bc3(hit.x), xyz(ra));
-                        io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
+                        io.st.first_pos[pid - rp.keep_pos_from] = f4{p.x, p.y, p.z, hit.x};
                     }
-                    if (pid >= rp.keep_id_from) io.st.first_id[pid] = in.blas & 0xffu;
+                    if (pid >= rp.keep_id_from) io.st.first_id[pid - rp.keep_id_from] = in.blas & 0xffu;
                 }
                 const DMaterial& m = sv.materials[in.material];
                 if (!rp.enable_nee || (flags & FLAG_LAST_DELTA) || bounce == 0u)       // integrator.rs:209-212
@@ -1335,8 +1332,8 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             const f3 p = fma3(rd, bc3(hit.x), ro);                                     // r.at(hit_info.t)
             if (bounce == 0u)                                                          // integrator.rs:181-185
             {
-                if (pid >= rp.keep_pos_from) io.st.first_pos[pid] = f4{p.x, p.y, p.z, hit.x};
-                if (pid >= rp.keep_id_from) io.st.first_id[pid] = in.blas & 0xffu;
+                if (pid >= rp.keep_pos_from) io.st.first_pos[pid - rp.keep_pos_from] = f4{p.x, p.y, p.z, hit.x};
+                if (pid >= rp.keep_id_from) io.st.first_id[pid - rp.keep_id_from] = in.blas & 0xffu;
             }
             const PixelId px = path_pixel(rp, pid);
             Stream rng{stream_key(rp.seed, px.gpixel, px.sample), asu(pw4.w)};
@@ -1617,12 +1614,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
             const f3 c = finalise(xyz(rad[j]));
             a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
             // (id << 16) | new once per sample: only the last two samples survive in 32 bits
-            if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid];
+            if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid - rp.keep_id_from];
         }
     }
     if (add_to_accum) accum[lp] = a;
     id[lp] = idv;
-    if (write_position) position[lp] = st.first_pos[(rp.batch_samples - 1u) * rp.local_pixels + lp];
+    if (write_position) position[lp] = st.first_pos[lp]; // the batch's last sample: (batch_samples - 1) * local_pixels + lp - keep_pos_from
 }
 
 __global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, const PathState st, f4* out)

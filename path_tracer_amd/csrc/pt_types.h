@@ -195,8 +195,8 @@ struct PathState
     uint8_t* occl;
     uint32_t* vstack;   // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
     f4* radiance;       // finished paths: accumulated.xyz (what integrate() returns before the finite check), dense by path id
-    f4* first_pos;      // first-hit xyz | t        (main.rs:205)
-    uint32_t* first_id;
+    f4* first_pos;      // first-hit xyz | t        (main.rs:205) of the batch's LAST sample: index = path id - keep_pos_from
+    uint32_t* first_id; // of the batch's last TWO samples (id history, main.rs:206): index = path id - keep_id_from
 };
 enum : uint32_t { FLAG_BOUNCE_MASK = 0xffffu, FLAG_LAST_DELTA = 1u << 16, FLAG_NEE_PENDING = 1u << 17, FLAG_BSDF_CAST = 1u << 18 };
 

@@ -26,7 +26,8 @@ enum pt_status
     PT_ERR_NONRIGID = -4, /* model matrix carries scale: model.rs:40-44 asserts scale == (1,1,1) */
     PT_ERR_LIMIT = -5,    /* scene exceeds a packing limit of the device layout */
     PT_ERR_IO = -6,       /* file cannot be read / written */
-    PT_ERR_PARSE = -7     /* malformed OBJ (the reference panics) */
+    PT_ERR_PARSE = -7,    /* malformed OBJ (the reference panics) */
+    PT_ERR_NCCL = -8      /* RCCL failure (library missing, communicator or collective error) */
 };
 
 /* Material enum of material.rs:80-89; GGX splits into its two GGXModel variants (material.rs:176-184). */
@@ -194,6 +195,31 @@ int pt_tlas_dump(pt_ctx* ctx, int which, uint32_t* n_nodes, uint32_t* root, floa
 int pt_light_cdf(pt_ctx* ctx, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap);
 int pt_triangle_dump(pt_ctx* ctx, int blas, uint32_t prim, float out36[36]);
 
+/* ---- several GPUs, one process  (src/main.rs:72,181-207: ONE process, all pixels independent) ---------------------- */
+/* The reference fans its pixel loop out over a thread pool inside one process.  pt_multi is that for GPUs: N contexts, one per
+ * device, rows dealt to them in strips of pt_config.strip_rows (rank/world_size of `cfg` are overwritten), one host thread per
+ * device while rendering, then ONE RCCL gather (ncclCommInitAll + ncclGather, xGMI) of the strip framebuffers to devices[0] and a
+ * de-interleave kernel there.  No collective runs while rendering; the counter-based RNG is keyed by the GLOBAL pixel, so the frame
+ * is bit-identical for any device count.
+ *   devices NULL: 0 .. n_devices-1.  The same device may be listed several times (contexts then share it and the gather is a
+ *   device-to-device copy instead of RCCL: RCCL refuses duplicate devices) — that is how one-GPU boxes test the assembly.
+ * Scene: make the Scene::new calls (pt_add_material / pt_add_model* / pt_build / pt_set_camera / pt_set_environment /
+ * pt_camera_input) on pt_multi_ctx(m, 0); pt_multi_render replicates the built scene, camera and environment to the other
+ * contexts whenever they changed.  Every other pt_* call on a member context is allowed but sees only that rank's rows. */
+typedef struct pt_multi pt_multi;
+pt_multi* pt_multi_create(const pt_config* cfg, const int32_t* devices, uint32_t n_devices);
+void pt_multi_destroy(pt_multi* m);
+const char* pt_multi_last_error(pt_multi* m);
+pt_ctx* pt_multi_ctx(pt_multi* m, uint32_t rank);
+/* pt_render for the whole frame: samples [first_sample, first_sample + n_samples) on every device, gather, and (data_rgba != NULL)
+ * the accumulated frame, height*width*4 floats, row 0 = bottom, copied to the host.  Blocking. */
+int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, float* data_rgba);
+/* the gathered frame of the last pt_multi_render on devices[0] (float4 per pixel) */
+int pt_multi_framebuffer_device_ptr(pt_multi* m, void** dev_ptr);
+int pt_multi_reset_accumulation(pt_multi* m);
+/* 1 if the last gather went through RCCL, 0 if it was device-to-device copies (duplicate devices) */
+int pt_multi_used_rccl(pt_multi* m);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 typedef struct pt_stats
 {
@@ -213,6 +239,7 @@ typedef struct pt_stats
                                         the shading pass answers them with that one slab test, tlas.rs:68-74) */
 } pt_stats;
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+int pt_multi_get_stats(pt_multi* m, pt_stats* sum);   /* counters summed over the devices; ms_total = the slowest device's */
 /* counter rows of the LAST wavefront batch, 16 words per bounce (diagnostic): [0] closest-queue slots, [2] shadow-queue slots,
  * [4] NEE-chain slots, [6] NEE-chain rays traced, [7] of those hitting a light, [8..12] shade-queue slots (terminal, lambert,
  * specular, dielectric, ggx), [13] closest rays traced, [14] shadow rays traced.  Slots include the holes producers return. */

@@ -32,6 +32,8 @@ EXPORTS = [
     "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
+    "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
+    "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl",
 ]
 
 
@@ -114,6 +116,18 @@ def lib():
         L.pt_camera_angles.argtypes = [vp, vp]
         L.pt_inv_projection.argtypes = [vp, vp]
         L.pt_present.argtypes = [vp, vp]
+        L.pt_multi_create.restype = vp
+        L.pt_multi_create.argtypes = [C.POINTER(Config), vp, u32]
+        L.pt_multi_destroy.argtypes = [vp]
+        L.pt_multi_last_error.restype = C.c_char_p
+        L.pt_multi_last_error.argtypes = [vp]
+        L.pt_multi_ctx.restype = vp
+        L.pt_multi_ctx.argtypes = [vp, u32]
+        L.pt_multi_render.argtypes = [vp, u32, u32, vp]
+        L.pt_multi_framebuffer_device_ptr.argtypes = [vp, C.POINTER(vp)]
+        L.pt_multi_reset_accumulation.argtypes = [vp]
+        L.pt_multi_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.pt_multi_used_rccl.argtypes = [vp]
         L.pt_post_velocity.argtypes = [vp, u32, u32, vp, vp, vp]
         L.pt_post_reproject.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
         L.pt_post_tonemap.argtypes = [vp, u32, u32, vp, vp]
@@ -197,9 +211,22 @@ class Renderer:
             raise PtError(r, self.L.pt_last_error(self.ctx).decode())
         return r
 
+    @classmethod
+    def attach(cls, ctx, cfg):
+        """Wrap a context somebody else owns (a member of a MultiRenderer): same calls, close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.cfg = cfg
+        self.ctx = C.c_void_p(ctx)
+        self.desc = None
+        self._materials = []
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "ctx", None):
-            self.L.pt_destroy(self.ctx)
+            if not getattr(self, "_borrowed", False):
+                self.L.pt_destroy(self.ctx)
             self.ctx = None
 
     def __del__(self):
@@ -452,3 +479,59 @@ class Renderer:
 
     def reset_stats(self):
         self._chk(self.L.pt_reset_stats(self.ctx))
+
+
+class MultiRenderer:
+    """One process, several devices (pt_multi): rows dealt to the devices in strips, one host thread per device while rendering, one
+    RCCL gather of the strip framebuffers to devices[0].  `devices` may list a device more than once (contexts then share it and the
+    gather is device-to-device copies): that is how the assembly is tested on a one-GPU box."""
+
+    def __init__(self, scene: SceneDesc, width: int, height: int, devices, **kw):
+        self.L = lib()
+        devices = [int(d) for d in devices]
+        kw.setdefault("strip_rows", 4)
+        cfg = Config(width, height, kw.get("max_bounces", 8), kw.get("n_sobol", 512), int(kw.get("enable_nee", True)), kw.get("seed", DEFAULT_SEED), 0, 1,
+                     kw["strip_rows"], kw.get("batch_spp", 0), -1, kw.get("flags", 0), 0, 0, kw.get("pipelines", 0), 0)
+        arr = (C.c_int32 * len(devices))(*devices)
+        self.m = C.c_void_p(self.L.pt_multi_create(C.byref(cfg), arr, len(devices)))
+        if not self.m:
+            raise PtError(-1, "pt_multi_create failed")
+        self.width, self.height, self.n = width, height, len(devices)
+        self.rank0 = Renderer.attach(self.L.pt_multi_ctx(self.m, 0), cfg)
+        for mod in scene.models:
+            self.rank0.add_model(mod)
+        self.rank0.rebuild()
+        if scene.camera is not None:
+            self.rank0.set_camera(scene.camera)
+
+    def _chk(self, r):
+        if r != 0:
+            raise PtError(r, self.L.pt_multi_last_error(self.m).decode())
+
+    def render(self, first_sample: int, n_samples: int, download=True):
+        out = np.zeros((self.height, self.width, 4), np.float32) if download else None
+        self._chk(self.L.pt_multi_render(self.m, first_sample, n_samples, _p(out)))
+        return out
+
+    def reset_accumulation(self):
+        self._chk(self.L.pt_multi_reset_accumulation(self.m))
+
+    def used_rccl(self) -> bool:
+        return bool(self.L.pt_multi_used_rccl(self.m))
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._chk(self.L.pt_multi_get_stats(self.m, C.byref(s)))
+        return s
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.rank0.close()
+            self.L.pt_multi_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -101,6 +101,8 @@ struct pt_ctx
     // frame
     std::vector<uint32_t> rows; // local row -> global row
     uint32_t local_pixels = 0;
+    uint32_t pad_rows = 0;      // rows of the largest strip set (rank 0's)
+    uint64_t scene_version = 0; // bumped by pt_build / camera / environment changes (pt_multi replicates on change)
     DevBuf d_accum, d_position, d_id;
     DevBuf d_input, d_velocity, d_output; // State::update textures (pt_frame)
 
@@ -146,6 +148,10 @@ void compute_rows(pt_ctx* c)
     for (uint32_t y = 0; y < g.height; ++y)
         if ((y / strip) % world == g.rank) c->rows.push_back(y);
     c->local_pixels = (uint32_t)c->rows.size() * g.width;
+    // rank 0 owns the most rows: every rank's strip framebuffer is allocated that large so that one equal-count gather moves them all
+    uint32_t r0 = 0;
+    for (uint32_t y = 0; y < g.height; ++y) r0 += ((y / strip) % world == 0u) ? 1u : 0u;
+    c->pad_rows = r0;
 }
 
 int normalise_config(pt_ctx* c, const pt_config* in)
@@ -297,7 +303,7 @@ TraceLaunch trace_launch(pt_ctx* c, int pipe = 0, bool side_stream = false)
 int ensure_frame(pt_ctx* c)
 {
     int r;
-    const size_t px = std::max<uint32_t>(c->local_pixels, 1);
+    const size_t px = std::max<size_t>(std::max<size_t>(c->local_pixels, (size_t)c->pad_rows * c->cfg.width), 1);
     const bool fresh = c->d_accum.bytes < px * 16;
     if ((r = dev_alloc(c, c->d_accum, px * 16))) return r;
     if ((r = dev_alloc(c, c->d_position, px * 16))) return r;
@@ -860,6 +866,7 @@ int pt_build(pt_ctx* c)
     std::string err;
     int r = c->scene.build(&err);
     c->scene_uploaded = false;
+    c->scene_version++;
     if (r) return fail(c, r == -5 ? PT_ERR_LIMIT : PT_ERR_STATE, err);
     return PT_OK;
 }
@@ -869,6 +876,7 @@ int pt_set_camera(pt_ctx* c, const float eye[3], const float target[3], float fo
     if (!c || !eye || !target) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->scene.set_camera(eye, target, fov_y_deg, aspect);
+    c->scene_version++;
     return PT_OK;
 }
 
@@ -879,11 +887,11 @@ int pt_camera_input(pt_ctx* c, int event, float a, float b, float dt)           
     if (!c->scene.camera.set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
     switch (event)
     {
-    case PT_EV_MOUSE_MOTION: c->scene.camera_rotate(a, b, dt); return 1;
-    case PT_EV_KEY_W: c->scene.camera_move(0.0f, 1.0f, dt); return 1;
-    case PT_EV_KEY_S: c->scene.camera_move(0.0f, -1.0f, dt); return 1;
-    case PT_EV_KEY_A: c->scene.camera_move(-1.0f, 0.0f, dt); return 1;
-    case PT_EV_KEY_D: c->scene.camera_move(1.0f, 0.0f, dt); return 1;
+    case PT_EV_MOUSE_MOTION: c->scene.camera_rotate(a, b, dt); c->scene_version++; return 1;
+    case PT_EV_KEY_W: c->scene.camera_move(0.0f, 1.0f, dt); c->scene_version++; return 1;
+    case PT_EV_KEY_S: c->scene.camera_move(0.0f, -1.0f, dt); c->scene_version++; return 1;
+    case PT_EV_KEY_A: c->scene.camera_move(-1.0f, 0.0f, dt); c->scene_version++; return 1;
+    case PT_EV_KEY_D: c->scene.camera_move(1.0f, 0.0f, dt); c->scene_version++; return 1;
     default: return 0;
     }
 }
@@ -903,6 +911,7 @@ int pt_set_environment(pt_ctx* c, uint32_t width, uint32_t height, const float* 
     if (!c) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->env_uploaded = false;
+    c->scene_version++;
     c->h_env.clear();
     c->env_w = c->env_h = 0;
     if (!rgb_linear || width == 0 || height == 0) return PT_OK;
@@ -1430,6 +1439,236 @@ int pt_triangle_dump(pt_ctx* c, int blas, uint32_t prim, float out36[36])
     std::memcpy(out36 + 12, t.p, 36);
     std::memcpy(out36 + 21, t.n, 36);
     for (int i = 30; i < 36; ++i) out36[i] = 0;
+    return PT_OK;
+}
+
+// ====================================================================================================== several devices, one process
+} // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <thread>
+
+namespace {
+// RCCL is loaded on first use: a single-device user of libptmi never maps it
+struct Rccl
+{
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string* err)
+    {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) { *err = std::string("librccl.so cannot be loaded: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Gather = (decltype(Gather))dlsym(lib, "ncclGather");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Gather || !GetErrorString) { *err = "librccl.so lacks an expected symbol"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+} // namespace
+
+struct pt_multi
+{
+    std::vector<pt_ctx*> ctx;
+    std::vector<int> devices;
+    std::string err;
+    bool distinct = true;                 // no device listed twice: the gather can go through RCCL
+    std::vector<ncclComm_t> comms;
+    uint64_t replicated_version = ~0ull;  // scene_version of ctx[0] the other contexts hold
+    DevBuf d_parts, d_full;               // on devices[0]: gathered padded strips, assembled frame
+    bool used_rccl = false;
+};
+
+namespace {
+int mfail(pt_multi* m, int code, const std::string& msg)
+{
+    m->err = msg;
+    return code;
+}
+// Scene::new happened on rank 0's context: every other context gets a copy of the built host scene, camera and environment
+int multi_replicate(pt_multi* m)
+{
+    pt_ctx* c0 = m->ctx[0];
+    if (m->replicated_version == c0->scene_version) return PT_OK;
+    for (size_t i = 1; i < m->ctx.size(); ++i)
+    {
+        pt_ctx* c = m->ctx[i];
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->scene = c0->scene;
+        c->scene_uploaded = false;
+        c->h_env = c0->h_env;
+        c->env_w = c0->env_w;
+        c->env_h = c0->env_h;
+        c->env_uploaded = false;
+        c->scene_version = c0->scene_version;
+    }
+    m->replicated_version = c0->scene_version;
+    return PT_OK;
+}
+} // namespace
+
+extern "C" {
+
+pt_multi* pt_multi_create(const pt_config* cfg, const int32_t* devices, uint32_t n_devices)
+{
+    if (!cfg || n_devices == 0 || n_devices > 64) return nullptr;
+    pt_multi* m = new (std::nothrow) pt_multi();
+    if (!m) return nullptr;
+    for (uint32_t i = 0; i < n_devices; ++i)
+    {
+        pt_config g = *cfg;
+        g.rank = i;
+        g.world_size = n_devices;
+        g.device = devices ? devices[i] : (int32_t)i;
+        pt_ctx* c = pt_create(&g);
+        if (!c) { pt_multi_destroy(m); return nullptr; }
+        m->ctx.push_back(c);
+        m->devices.push_back(g.device);
+        for (uint32_t j = 0; j < i; ++j) m->distinct = m->distinct && m->devices[j] != g.device;
+    }
+    return m;
+}
+
+void pt_multi_destroy(pt_multi* m)
+{
+    if (!m) return;
+    if (!m->comms.empty())
+    {
+        for (ncclComm_t k : m->comms) (void)g_rccl.CommDestroy(k);
+    }
+    if (!m->ctx.empty() && m->ctx[0]->dev_ready)
+    {
+        (void)hipSetDevice(m->ctx[0]->device);
+        dev_free(m->d_parts);
+        dev_free(m->d_full);
+    }
+    for (pt_ctx* c : m->ctx) pt_destroy(c);
+    delete m;
+}
+
+const char* pt_multi_last_error(pt_multi* m) { return m ? m->err.c_str() : "null pt_multi"; }
+pt_ctx* pt_multi_ctx(pt_multi* m, uint32_t rank) { return (m && rank < m->ctx.size()) ? m->ctx[rank] : nullptr; }
+int pt_multi_used_rccl(pt_multi* m) { return m ? (m->used_rccl ? 1 : 0) : PT_ERR_ARG; }
+
+int pt_multi_reset_accumulation(pt_multi* m)
+{
+    if (!m) return PT_ERR_ARG;
+    for (pt_ctx* c : m->ctx)
+    {
+        int r = pt_reset_accumulation(c);
+        if (r) return mfail(m, r, pt_last_error(c));
+    }
+    return PT_OK;
+}
+
+int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, float* data_rgba)
+{
+    if (!m) return PT_ERR_ARG;
+    int r;
+    if ((r = multi_replicate(m))) return r;
+    const size_t n = m->ctx.size();
+    // one host thread per device (the reference: one rayon pool, src/main.rs:72); no collective while rendering
+    std::vector<int> rc(n, PT_OK);
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = pt_render_device(m->ctx[i], first_sample, n_samples); });
+        rc[0] = pt_render_device(m->ctx[0], first_sample, n_samples);
+        for (std::thread& t : th) t.join();
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (rc[i]) return mfail(m, rc[i], std::string("device ") + std::to_string(m->devices[i]) + ": " + pt_last_error(m->ctx[i]));
+
+    // ---- gather: every rank's padded strip framebuffer to devices[0], then de-interleave there
+    pt_ctx* c0 = m->ctx[0];
+    const pt_config& g = c0->cfg;
+    const size_t part_px = (size_t)c0->pad_rows * g.width, full_px = (size_t)g.width * g.height;
+    for (pt_ctx* c : m->ctx)
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if ((r = ensure_device(c)) || (r = ensure_frame(c))) return mfail(m, r, pt_last_error(c));
+    }
+    HIPCHK(c0, hipSetDevice(c0->device));
+    if ((r = dev_alloc(c0, m->d_parts, std::max<size_t>(part_px * n, 1) * 16)) || (r = dev_alloc(c0, m->d_full, std::max<size_t>(full_px, 1) * 16))) return mfail(m, r, pt_last_error(c0));
+    m->used_rccl = false;
+    if (m->distinct)
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        std::string e;
+        if (!g_rccl.load(&e)) return mfail(m, PT_ERR_NCCL, e);
+        if (m->comms.empty())
+        {
+            m->comms.resize(n);
+            const ncclResult_t nr = g_rccl.CommInitAll(m->comms.data(), (int)n, m->devices.data());
+            if (nr != ncclSuccess) { m->comms.clear(); return mfail(m, PT_ERR_NCCL, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr)); }
+        }
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (size_t i = 0; i < n && nr == ncclSuccess; ++i)
+        {
+            pt_ctx* c = m->ctx[i];
+            if (hipSetDevice(c->device) != hipSuccess) { nr = ncclUnhandledCudaError; break; }
+            nr = g_rccl.Gather(c->d_accum.p, i == 0 ? m->d_parts.p : nullptr, part_px * 4, ncclFloat, 0, m->comms[i], c->stream);
+        }
+        const ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return mfail(m, PT_ERR_NCCL, std::string("ncclGather: ") + g_rccl.GetErrorString(nr));
+        m->used_rccl = true;
+        for (size_t i = 1; i < n; ++i)
+        {
+            HIPCHK(c0, hipSetDevice(m->ctx[i]->device));
+            HIPCHK(c0, hipStreamSynchronize(m->ctx[i]->stream));
+        }
+        HIPCHK(c0, hipSetDevice(c0->device));
+    }
+    else
+    {
+        // contexts sharing a device (or RCCL ruled out): plain device-to-device copies on devices[0]'s stream
+        for (size_t i = 0; i < n; ++i)
+            HIPCHK(c0, hipMemcpyAsync((uint8_t*)m->d_parts.p + i * part_px * 16, m->ctx[i]->d_accum.p, part_px * 16, hipMemcpyDeviceToDevice, c0->stream));
+    }
+    launch_post_deinterleave(c0->stream, g.width, g.height, (uint32_t)n, g.strip_rows, c0->pad_rows, (const f4*)m->d_parts.p, (f4*)m->d_full.p);
+    if (data_rgba) HIPCHK(c0, hipMemcpyAsync(data_rgba, m->d_full.p, full_px * 16, hipMemcpyDeviceToHost, c0->stream));
+    HIPCHK(c0, hipStreamSynchronize(c0->stream));
+    HIPCHK(c0, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_multi_framebuffer_device_ptr(pt_multi* m, void** dev_ptr)
+{
+    if (!m || !dev_ptr) return PT_ERR_ARG;
+    if (!m->d_full.p) return mfail(m, PT_ERR_STATE, "pt_multi_render has not been called");
+    *dev_ptr = m->d_full.p;
+    return PT_OK;
+}
+
+int pt_multi_get_stats(pt_multi* m, pt_stats* sum)
+{
+    if (!m || !sum) return PT_ERR_ARG;
+    *sum = pt_stats();
+    for (pt_ctx* c : m->ctx)
+    {
+        const pt_stats& s = c->stats;
+        sum->rays_closest += s.rays_closest; sum->rays_any += s.rays_any; sum->rays_light_closest += s.rays_light_closest;
+        sum->rays_light_closest_traced += s.rays_light_closest_traced; sum->paths += s.paths;
+        sum->launches_trace_closest += s.launches_trace_closest; sum->ms_trace_closest += s.ms_trace_closest;
+        sum->ms_trace_any += s.ms_trace_any; sum->ms_trace_light += s.ms_trace_light; sum->ms_shade += s.ms_shade;
+        sum->ms_generate += s.ms_generate; sum->ms_accumulate += s.ms_accumulate;
+        sum->ms_total = std::max(sum->ms_total, s.ms_total);
+        sum->state_bytes += s.state_bytes;
+        sum->scene_bytes = s.scene_bytes; sum->lds_scene = s.lds_scene; sum->stack_entries = s.stack_entries;
+    }
     return PT_OK;
 }
 

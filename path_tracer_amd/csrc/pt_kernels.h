@@ -70,6 +70,7 @@ void launch_post_velocity(hipStream_t s, int w, int h, const f4* position, const
 void launch_post_reproject(hipStream_t s, int w, int h, const f4* input, const f4* accum, const float* velocity_xy, const uint32_t* id, f4* output);
 void launch_post_tonemap(hipStream_t s, uint32_t n, const f4* accum, f4* out);
 void launch_post_rgb8(hipStream_t s, uint32_t n, const f4* accum, uint8_t* out);
+void launch_post_deinterleave(hipStream_t s, uint32_t w, uint32_t h, uint32_t world, uint32_t strip, uint32_t pad_rows, const f4* parts, f4* full);
 
 // unit hooks
 // n_and_heads: word 0 = number of rays, words [32, 32 + kHeadWordsPerQueue) = zeroed claim cursors

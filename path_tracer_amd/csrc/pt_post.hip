@@ -227,8 +227,24 @@ __global__ void __launch_bounds__(256) k_post_rgb8(uint32_t n, const f4* __restr
         out[(size_t)i * 3u + k] = (uint8_t)to_u8_sat(pow_det(gt_curve_rs(ch[k], 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f), g) * 255.0f);
 }
 
+// strips gathered from `world` ranks (rank r's rows, padded to pad_rows, at parts + r * pad_rows * w) -> the whole frame, row-major:
+// global row y belongs to rank (y / strip) % world and is that rank's local row (y / strip / world) * strip + y % strip  (compute_rows)
+__global__ void __launch_bounds__(256) k_post_deinterleave(uint32_t w, uint32_t h, uint32_t world, uint32_t strip, uint32_t pad_rows,
+                                                            const f4* __restrict__ parts, f4* __restrict__ full)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const uint32_t y = i / w, x = i - y * w;
+    const uint32_t st = y / strip, rank = st % world, ly = (st / world) * strip + (y - st * strip);
+    full[i] = parts[((size_t)rank * pad_rows + ly) * w + x];
+}
+
 } // namespace
 
+void launch_post_deinterleave(hipStream_t s, uint32_t w, uint32_t h, uint32_t world, uint32_t strip, uint32_t pad_rows, const f4* parts, f4* full)
+{
+    hipLaunchKernelGGL(k_post_deinterleave, dim3((w * h + 255u) / 256u), dim3(256), 0, s, w, h, world, strip, pad_rows, parts, full);
+}
 void launch_post_rgb8(hipStream_t s, uint32_t n, const f4* accum, uint8_t* out)
 {
     hipLaunchKernelGGL(k_post_rgb8, dim3((n + 255u) / 256u), dim3(256), 0, s, n, accum, out);

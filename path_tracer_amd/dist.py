@@ -29,24 +29,34 @@ def wrap_device_framebuffer(ptr: int, rows: int, width: int, device) -> torch.Te
     return torch.as_tensor(_DevPtr(ptr, (rows, width, 4)), device=device)
 
 
+def pad_strips(local: torch.Tensor, height: int, width: int, world_size: int, strip_rows: int) -> torch.Tensor:
+    """A rank's (local_rows, width, 4) strips padded with zero rows to the largest rank's row count: gather wants equal chunks."""
+    pad_rows = max_rows(height, world_size, strip_rows)
+    if local.shape[0] == pad_rows:
+        return local.contiguous()
+    send = torch.zeros((pad_rows, width, 4), dtype=local.dtype, device=local.device)
+    send[: local.shape[0]] = local
+    return send
+
+
+def assemble_strips(parts, height: int, width: int, world_size: int, strip_rows: int) -> torch.Tensor:
+    """De-interleave the gathered (padded) strip buffers of all ranks into the (height, width, 4) frame, on their device."""
+    full = torch.empty((height, width, 4), dtype=parts[0].dtype, device=parts[0].device)
+    for r in range(world_size):
+        rows = torch.from_numpy(rows_of_rank(height, r, world_size, strip_rows)).to(parts[0].device)
+        full[rows] = parts[r][: len(rows)]
+    return full
+
+
 def gather_framebuffer(local: torch.Tensor, height: int, width: int, rank: int, world_size: int, strip_rows: int, dst: int = 0):
     """Gather the per-rank (local_rows, width, 4) accumulation buffers on `dst` and de-interleave into (height, width, 4).
     Returns the full framebuffer on dst and None elsewhere.  Equal-size chunks: ranks with fewer rows pad."""
     if world_size == 1:
         return local
-    pad_rows = max_rows(height, world_size, strip_rows)
-    send = local
-    if local.shape[0] != pad_rows:
-        send = torch.zeros((pad_rows, width, 4), dtype=local.dtype, device=local.device)
-        send[: local.shape[0]] = local
-    send = send.contiguous()
+    send = pad_strips(local, height, width, world_size, strip_rows)
     if rank == dst:
         parts = [torch.empty_like(send) for _ in range(world_size)]
         dist.gather(send, parts, dst=dst)
-        full = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
-        for r in range(world_size):
-            rows = torch.from_numpy(rows_of_rank(height, r, world_size, strip_rows)).to(local.device)
-            full[rows] = parts[r][: len(rows)]
-        return full
+        return assemble_strips(parts, height, width, world_size, strip_rows)
     dist.gather(send, None, dst=dst)
     return None

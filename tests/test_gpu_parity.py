@@ -509,6 +509,55 @@ def test_framebuffer_is_visible_to_torch_in_place(api, cornell64):
     r.set_stream(None)
 
 
+def test_multi_device_context_through_the_c_abi(api, oracle_mod):
+    """pt_multi: one process driving N contexts.  (a) one device through RCCL (a one-rank communicator; ncclGather to itself),
+    (b) three contexts SHARING the device: strips of every rank gathered by device copies and de-interleaved on the GPU.  Both must
+    reproduce the single-context frame bit for bit (the RNG is keyed by the global pixel), odd height so that ranks own unequal rows."""
+    from path_tracer_amd import scenes
+    W, H = 96, 70
+    sc = scenes.cornell_mixed(W, H)
+    want = oracle_mod.Oracle(sc).render(W, H, 5, max_bounces=6)[0]
+    one = api.MultiRenderer(sc, W, H, [0], max_bounces=6)
+    got = one.render(0, 5)
+    assert one.used_rccl(), "a one-device pt_multi gathers through RCCL"
+    assert_bit_equal(got, want, "pt_multi, 1 device, RCCL gather")
+    st = one.stats()
+    one.close()
+    three = api.MultiRenderer(sc, W, H, [0, 0, 0], max_bounces=6, strip_rows=4)
+    three.render(0, 2, download=False)
+    got3 = three.render(2, 3)
+    assert not three.used_rccl()
+    assert_bit_equal(got3, want, "pt_multi, three contexts on one device, resumed accumulation")
+    st3 = three.stats()
+    assert (st3.rays_closest, st3.rays_any, st3.rays_light_closest, st3.paths) == (st.rays_closest, st.rays_any, st.rays_light_closest, st.paths)
+    three.close()
+
+
+def test_gather_pad_and_deinterleave_run_on_device_tensors(api, cornell64):
+    """path_tracer_amd.dist: the padding of unequal strip sets and the de-interleave of gathered strips, on DEVICE tensors that view
+    the framebuffers of three contexts (world_size 3 emulated in one process; the collective itself is torch.distributed's)."""
+    import torch
+    from path_tracer_amd import dist as ptdist
+    W, H, world, strip = 64, 50, 3, 4
+    ref = api.Renderer(cornell64, W, H, max_bounces=4).render(0, 3)[0]
+    dev = torch.device("cuda", 0)
+    parts = []
+    keep = []
+    for rank in range(world):
+        r = api.Renderer(cornell64, W, H, max_bounces=4, rank=rank, world_size=world, strip_rows=strip)
+        r.render_device(0, 3); r.synchronize()
+        ptr, n = r.accum_device_ptr()
+        rows = len(r.local_rows())
+        assert n == rows * W
+        local = ptdist.wrap_device_framebuffer(ptr, rows, W, dev)
+        parts.append(ptdist.pad_strips(local, H, W, world, strip).clone())
+        keep.append(r)
+    assert len({tuple(p.shape) for p in parts}) == 1 and parts[0].is_cuda
+    full = ptdist.assemble_strips(parts, H, W, world, strip)
+    assert full.is_cuda
+    assert_bit_equal(full.cpu().numpy(), ref, "strips of three ranks padded and de-interleaved on the device")
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_scenes_bit_exact(api, oracle_mod, seed):
     """fuzz: several lights, instanced quarter-turn transforms, every material kind, nested media"""

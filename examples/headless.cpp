@@ -3,11 +3,13 @@
 // Everything goes through include/ptmi.hpp, i.e. the C-ABI of libptmi.
 //
 //   examples/headless [--width W] [--height H] [--frames N] [--bounces B] [--move] [--models DIR] [--out file.png]
+//   examples/headless --gpus N [--devices a,b,..] --spp S ...   the same scene, S samples per pixel on N GPUs of this process (pt_multi)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ptmi.hpp"
 
@@ -17,6 +19,8 @@ int main(int argc, char** argv)
 {
     uint32_t width = 1920, height = 1080, frames = 64, bounces = 8; // IMAGE_WIDTH/HEIGHT main.rs:44-45; the reference's MAX_BOUNCES is 1024
     bool move = false;
+    uint32_t gpus = 0, spp = 64;
+    std::vector<int32_t> devices;
     std::string models_dir = "models/cornell", out = "";
     for (int i = 1; i < argc; ++i)
     {
@@ -32,6 +36,13 @@ int main(int argc, char** argv)
         else if (a == "--models") models_dir = next("--models");
         else if (a == "--out") out = next("--out");
         else if (a == "--move") move = true;
+        else if (a == "--gpus") gpus = (uint32_t)std::atoi(next("--gpus"));
+        else if (a == "--spp") spp = (uint32_t)std::atoi(next("--spp"));
+        else if (a == "--devices")
+        {
+            const std::string list = next("--devices");
+            for (size_t p0 = 0; p0 < list.size();) { const size_t p1 = list.find(',', p0); devices.push_back(std::atoi(list.substr(p0, p1 - p0).c_str())); if (p1 == std::string::npos) break; p0 = p1 + 1; }
+        }
         else if (a == "--help" || a == "-h")
         {
             std::printf("usage: %s [--width W] [--height H] [--frames N] [--bounces B] [--move] [--models DIR] [--out file.png]\n", argv[0]);
@@ -61,6 +72,23 @@ int main(int argc, char** argv)
         // Camera  main.rs:119-128
         const Vec3A look_from{0.0f, 50.0f, 1000.0f}, look_at{0.0f, 50.0f, 0.0f};
         const Camera cam = Camera::New(look_from, look_at, 60.0f, (float)width / (float)height, 0.0f, 950.0f);
+        if (gpus > 0 || !devices.empty())
+        {
+            // several GPUs, one process: rows dealt to the devices in strips, one RCCL gather of the framebuffer (pt_multi)
+            if (devices.empty()) for (uint32_t d = 0; d < gpus; ++d) devices.push_back((int32_t)d);
+            MultiRenderer multi(scene, cam, width, height, bounces, devices);
+            multi.render(0, 1);                                  // scene upload, RCCL communicator set-up
+            multi.reset_accumulation();
+            const auto m0 = std::chrono::steady_clock::now();
+            multi.render(0, spp);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
+            const pt_stats st = multi.stats();
+            const double rays = (double)st.rays_closest + (double)st.rays_any + (double)st.rays_light_closest;
+            std::printf("{\"gpus\": %zu, \"rccl\": %s, \"spp\": %u, \"width\": %u, \"height\": %u, \"ms\": %.3f, \"Mray_per_s\": %.1f}\n", devices.size(),
+                        multi.used_rccl() ? "true" : "false", spp, width, height, 1e3 * sec, rays * (double)spp / (double)(spp + 1) / sec / 1e6);
+            if (!out.empty()) multi.write_image(out);
+            return 0;
+        }
         Renderer renderer(scene, cam, width, height, bounces);
         Mat4 last_inv_proj = renderer.inv_projection();
 

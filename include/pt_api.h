@@ -217,6 +217,7 @@ int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, floa
 /* the gathered frame of the last pt_multi_render on devices[0] (float4 per pixel) */
 int pt_multi_framebuffer_device_ptr(pt_multi* m, void** dev_ptr);
 int pt_multi_reset_accumulation(pt_multi* m);
+int pt_multi_write_image(pt_multi* m, const char* path); /* pt_write_image of the gathered frame */
 /* 1 if the last gather went through RCCL, 0 if it was device-to-device copies (duplicate devices) */
 int pt_multi_used_rccl(pt_multi* m);
 

@@ -133,6 +133,24 @@ struct Frame
     std::vector<uint32_t> id;          // W*H: (old << 16) | new                                        main.rs:137,206
 };
 
+// Scene::new on a context: materials in first-use order, models, pt_build
+inline void upload(pt_ctx* ctx_, const Scene& scene)
+{
+    auto check = [&](int r) { if (r < 0) throw Error(r, pt_last_error(ctx_)); return r; };
+        std::vector<Material> mats; // distinct materials in first-use order
+        for (const Model& m : scene.models)
+        {
+            size_t idx = 0;
+            while (idx < mats.size() && !(mats[idx] == m.material)) ++idx;
+            if (idx == mats.size()) { mats.push_back(m.material); check(pt_add_material(ctx_, &m.material.d)); }
+            const float* mat = m.matrices.empty() ? nullptr : m.matrices[0].m.data();
+            const uint32_t n_inst = (uint32_t)m.matrices.size();
+            if (!m.path.empty()) check(pt_add_model_obj(ctx_, m.path.c_str(), (int)idx, mat, n_inst));
+            else check(pt_add_model(ctx_, m.positions.data(), m.normals.data(), (uint32_t)(m.positions.size() / 9), (int)idx, mat, n_inst));
+        }
+        check(pt_build(ctx_));
+}
+
 // owns a pt_ctx: Scene::new + the wavefront state of main.rs's loop
 class Renderer
 {
@@ -146,18 +164,7 @@ public:
         ctx_ = pt_create(&cfg);
         if (!ctx_) throw Error(PT_ERR_ARG, "pt_create failed (bad configuration)");
         width_ = width; height_ = height;
-        std::vector<Material> mats; // distinct materials in first-use order
-        for (const Model& m : scene.models)
-        {
-            size_t idx = 0;
-            while (idx < mats.size() && !(mats[idx] == m.material)) ++idx;
-            if (idx == mats.size()) { mats.push_back(m.material); check(pt_add_material(ctx_, &m.material.d)); }
-            const float* mat = m.matrices.empty() ? nullptr : m.matrices[0].m.data();
-            const uint32_t n_inst = (uint32_t)m.matrices.size();
-            if (!m.path.empty()) check(pt_add_model_obj(ctx_, m.path.c_str(), (int)idx, mat, n_inst));
-            else check(pt_add_model(ctx_, m.positions.data(), m.normals.data(), (uint32_t)(m.positions.size() / 9), (int)idx, mat, n_inst));
-        }
-        check(pt_build(ctx_));
+        upload(ctx_, scene);
         set_camera(cam);
     }
     ~Renderer() { if (ctx_) pt_destroy(ctx_); }
@@ -200,6 +207,50 @@ private:
         return r;
     }
     pt_ctx* ctx_ = nullptr;
+    uint32_t width_ = 0, height_ = 0;
+};
+
+// owns a pt_multi: the same pixel loop fanned out over several GPUs of one process (the reference fans it out over the threads of
+// one rayon pool, main.rs:72,181); rows are dealt to the devices in strips, one RCCL gather per render
+class MultiRenderer
+{
+public:
+    MultiRenderer(const Scene& scene, const Camera& cam, uint32_t width, uint32_t height, uint32_t max_bounces, const std::vector<int32_t>& devices,
+                  uint32_t n_sobol = 512, bool enable_nee = true, uint64_t seed = 0x5EED5EEDull)
+    {
+        pt_config cfg{};
+        cfg.width = width; cfg.height = height; cfg.max_bounces = max_bounces; cfg.n_sobol = n_sobol; cfg.enable_nee = enable_nee ? 1u : 0u;
+        cfg.seed = seed; cfg.strip_rows = 4; cfg.device = -1;
+        m_ = pt_multi_create(&cfg, devices.data(), (uint32_t)devices.size());
+        if (!m_) throw Error(PT_ERR_ARG, "pt_multi_create failed (bad configuration)");
+        width_ = width; height_ = height;
+        pt_ctx* c0 = pt_multi_ctx(m_, 0);
+        upload(c0, scene);
+        const float eye[3] = {cam.origin.x, cam.origin.y, cam.origin.z}, tgt[3] = {cam.target.x, cam.target.y, cam.target.z};
+        if (pt_set_camera(c0, eye, tgt, cam.fov, cam.aspect_ratio) < 0) throw Error(PT_ERR_STATE, pt_last_error(c0));
+    }
+    ~MultiRenderer() { if (m_) pt_multi_destroy(m_); }
+    MultiRenderer(const MultiRenderer&) = delete;
+    MultiRenderer& operator=(const MultiRenderer&) = delete;
+    // samples [first_sample, first_sample + n_samples) of every pixel on all devices, gathered on the first; `out` (W*H*4) optional
+    void render(uint32_t first_sample, uint32_t n_samples, std::vector<float>* out = nullptr)
+    {
+        if (out) out->resize((size_t)width_ * height_ * 4);
+        check(pt_multi_render(m_, first_sample, n_samples, out ? out->data() : nullptr));
+    }
+    void reset_accumulation() { check(pt_multi_reset_accumulation(m_)); }
+    void write_image(const std::string& path) { check(pt_multi_write_image(m_, path.c_str())); }
+    bool used_rccl() const { return pt_multi_used_rccl(m_) == 1; }
+    pt_stats stats() const { pt_stats s{}; check(pt_multi_get_stats(m_, &s)); return s; }
+    pt_multi* handle() const { return m_; }
+
+private:
+    int check(int r) const
+    {
+        if (r < 0) throw Error(r, pt_multi_last_error(m_));
+        return r;
+    }
+    pt_multi* m_ = nullptr;
     uint32_t width_ = 0, height_ = 0;
 };
 

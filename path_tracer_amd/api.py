@@ -33,7 +33,7 @@ EXPORTS = [
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
-    "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl",
+    "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl", "pt_multi_write_image",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
         L.pt_multi_reset_accumulation.argtypes = [vp]
         L.pt_multi_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_multi_used_rccl.argtypes = [vp]
+        L.pt_multi_write_image.argtypes = [vp, C.c_char_p]
         L.pt_post_velocity.argtypes = [vp, u32, u32, vp, vp, vp]
         L.pt_post_reproject.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
         L.pt_post_tonemap.argtypes = [vp, u32, u32, vp, vp]
@@ -515,6 +516,9 @@ class MultiRenderer:
 
     def reset_accumulation(self):
         self._chk(self.L.pt_multi_reset_accumulation(self.m))
+
+    def write_image(self, path):
+        self._chk(self.L.pt_multi_write_image(self.m, str(path).encode()))
 
     def used_rccl(self) -> bool:
         return bool(self.L.pt_multi_used_rccl(self.m))

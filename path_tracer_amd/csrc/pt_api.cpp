@@ -1645,6 +1645,27 @@ int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, floa
     return PT_OK;
 }
 
+int pt_multi_write_image(pt_multi* m, const char* path)
+{
+    if (!m || !path) return PT_ERR_ARG;
+    if (!m->d_full.p) return mfail(m, PT_ERR_STATE, "pt_multi_render has not been called");
+    pt_ctx* c0 = m->ctx[0];
+    const size_t px = (size_t)c0->cfg.width * c0->cfg.height;
+    HIPCHK(c0, hipSetDevice(c0->device));
+    DevBuf d_rgb;
+    int r = dev_alloc(c0, d_rgb, px * 3);
+    if (r) return mfail(m, r, pt_last_error(c0));
+    launch_post_rgb8(c0->stream, (uint32_t)px, (const f4*)m->d_full.p, (uint8_t*)d_rgb.p);   // ImageHelper::write_image  image_helper.rs:37-58
+    std::vector<uint8_t> host(px * 3);
+    hipError_t e = hipMemcpyAsync(host.data(), d_rgb.p, px * 3, hipMemcpyDeviceToHost, c0->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+    dev_free(d_rgb);
+    if (e != hipSuccess) return mfail(m, PT_ERR_HIP, hipGetErrorString(e));
+    std::string err;
+    if (!write_png_rgb8(path, host.data(), c0->cfg.width, c0->cfg.height, &err)) return mfail(m, PT_ERR_IO, err);
+    return PT_OK;
+}
+
 int pt_multi_framebuffer_device_ptr(pt_multi* m, void** dev_ptr)
 {
     if (!m || !dev_ptr) return PT_ERR_ARG;

@@ -226,6 +226,28 @@ def test_cpp_host_driver_renders_what_the_oracle_renders(api, oracle_mod, tmp_pa
     assert np.array_equal(_read_png(out_png), oracle_mod.post_rgb8(acc))
 
 
+@pytest.mark.parametrize("args,rccl", [(["--gpus", "1"], "true"), (["--devices", "0,0,0"], "false")])
+def test_cpp_host_driver_on_several_devices(api, oracle_mod, tmp_path, args, rccl):
+    """examples/headless --gpus N: the C++ host side over pt_multi (one process, N contexts, one gather).  One device goes through RCCL;
+    three contexts sharing the device exercise the strip assembly.  The PNG must hold the oracle's bytes for the same samples."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from path_tracer_amd import build as B, scenes
+    from path_tracer_amd.scene_desc import Model, SceneDesc
+    W, H, SPP, BOUNCES = 96, 62, 6, 5
+    exe = B.build_host_driver()
+    out_png = tmp_path / "multi.png"
+    run = subprocess.run([exe, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--bounces", str(BOUNCES), "--out", str(out_png)] + args,
+                         capture_output=True, text=True, cwd=ROOT)
+    assert run.returncode == 0, run.stderr
+    assert f'"rccl": {rccl}' in run.stdout and f'"spp": {SPP}' in run.stdout
+    src = scenes.cornell_models()
+    sc = SceneDesc.new([Model.from_obj(os.path.join(ROOT, "models", "cornell", m.name + ".obj"), m.material) for m in src], scenes.reference_camera(W / H))
+    acc = oracle_mod.Oracle(sc).render(W, H, SPP, max_bounces=BOUNCES)[0]
+    assert np.array_equal(_read_png(out_png), oracle_mod.post_rgb8(acc))
+
+
 def test_frame_needs_the_whole_image_on_one_rank(api, cornell64):
     r = api.Renderer(cornell64, 64, 64, rank=0, world_size=2)
     with pytest.raises(api.PtError) as e:

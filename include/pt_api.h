@@ -80,7 +80,8 @@ enum
 {
     PT_FLAG_TIMING = 1u,       /* bracket every world closest-hit launch with HIP events on the launch stream (ms_trace_closest) */
     PT_FLAG_NO_LDS_SCENE = 2u, /* force BVH reads from global memory even when the scene fits LDS */
-    PT_FLAG_TIMING_ALL = 4u    /* bracket every kernel launch (adds ~10 us of idle per launch; diagnostic) */
+    PT_FLAG_TIMING_ALL = 4u,   /* bracket every kernel launch (adds ~10 us of idle per launch; diagnostic) */
+    PT_FLAG_NO_PRIMARY_CULL = 8u /* generate and trace the camera rays of EVERY pixel, also where they provably miss the scene's bounds */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
@@ -238,6 +239,8 @@ typedef struct pt_stats
     uint64_t state_bytes;            /* wavefront state + queues resident in HBM */
     uint64_t rays_light_closest_traced; /* of rays_light_closest, those that went through the lights TLAS (the others miss its root box:
                                         the shading pass answers them with that one slab test, tlas.rs:68-74) */
+    uint64_t rays_primary_culled;    /* of rays_closest, camera rays of pixels whose every ray misses the world's root box: answered by
+                                        the host's projection of that box onto the image plane, never generated */
 } pt_stats;
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 int pt_multi_get_stats(pt_multi* m, pt_stats* sum);   /* counters summed over the devices; ms_total = the slowest device's */

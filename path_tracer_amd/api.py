@@ -23,6 +23,7 @@ PT_OK = 0
 FLAG_TIMING = 1
 FLAG_NO_LDS_SCENE = 2
 FLAG_TIMING_ALL = 4
+FLAG_NO_PRIMARY_CULL = 8
 DEFAULT_SEED = 0x5EED5EED
 
 # every symbol include/pt_api.h declares
@@ -57,7 +58,7 @@ class Stats(C.Structure):
                 ("launches_trace_closest", C.c_uint64), ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double),
                 ("ms_trace_light", C.c_double), ("ms_shade", C.c_double), ("ms_generate", C.c_double), ("ms_accumulate", C.c_double),
                 ("ms_total", C.c_double), ("scene_bytes", C.c_uint64), ("lds_scene", C.c_uint32), ("stack_entries", C.c_uint32),
-                ("state_bytes", C.c_uint64), ("rays_light_closest_traced", C.c_uint64)]
+                ("state_bytes", C.c_uint64), ("rays_light_closest_traced", C.c_uint64), ("rays_primary_culled", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,7 +80,7 @@ struct pt_ctx
         size_t state_bytes = 0;
         bool busy = false;              // a batch has been launched and not yet harvested
         uint32_t busy_rows = 0;
-        uint64_t busy_paths = 0;
+        uint64_t busy_paths = 0, busy_culled = 0;
     };
     static constexpr int kMaxPipes = 4;
     Pipe pipe[kMaxPipes];
@@ -300,6 +301,89 @@ TraceLaunch trace_launch(pt_ctx* c, int pipe = 0, bool side_stream = false)
     return tl;
 }
 
+// Camera rays are generated only where they can hit something: the world TLAS's root box is projected onto the image plane (its
+// eight corners through the inverse of the camera's ray matrix, in binary64) and the pixel rectangle that contains the projection,
+// grown by a margin of three pixels, is the ACTIVE rectangle; every camera ray of a pixel outside it misses the root box — which is
+// all TLAS::intersect would find out (tlas.rs:68-72) — so its sample is the miss result of integrator.rs:263-266 and k_accumulate
+// adds exactly that.  Why this is safe: the root box is convex and in front of the camera, a projective map keeps its image inside
+// the hull (hence the bounding rectangle) of the projected corners, a jittered sample lies within half a pixel of its pixel centre,
+// and a ray that clears the box by more than two pixels of angle (> 1e-3 rad at 1080p) fails the binary32 slab test by a margin six
+// orders above its rounding error.  Not done when an environment map is set (a miss then needs its own direction), when a corner
+// is not safely in front of the camera, or with PT_FLAG_NO_PRIMARY_CULL.
+struct ActiveRect { uint32_t x0, w, ly0, rows; };
+ActiveRect active_rect(pt_ctx* c)
+{
+    const uint32_t W = c->cfg.width, H = c->cfg.height, local_rows = (uint32_t)c->rows.size();
+    const ActiveRect full{0u, W, 0u, local_rows};
+    if ((c->cfg.flags & PT_FLAG_NO_PRIMARY_CULL) || c->env_w || !c->scene.built || !c->scene.camera.set) return full;
+    const FlatScene& f = c->scene.flat;
+    if (f.world_root == MISS_ID || f.world_root >= f.nodes.size()) return full;
+    const DNode& root = f.nodes[f.world_root];
+    // M maps NDC (nx, ny, 0, 1) to a homogeneous world point on the image plane (k_generate); invert it in binary64
+    double m[16], inv[16];
+    for (int i = 0; i < 16; ++i) m[i] = c->scene.camera.ray_matrix[i];
+    {
+        // Gauss-Jordan on the column-major 4x4 (treated as a[row][col] = m[col * 4 + row])
+        double a[4][8];
+        for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) { a[r][k] = m[k * 4 + r]; a[r][4 + k] = r == k ? 1.0 : 0.0; }
+        for (int col = 0; col < 4; ++col)
+        {
+            int piv = col;
+            for (int r = col + 1; r < 4; ++r)
+                if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+            if (std::fabs(a[piv][col]) < 1e-300) return full;
+            for (int k = 0; k < 8; ++k) std::swap(a[col][k], a[piv][k]);
+            const double d = a[col][col];
+            for (int k = 0; k < 8; ++k) a[col][k] /= d;
+            for (int r = 0; r < 4; ++r)
+                if (r != col)
+                {
+                    const double fct = a[r][col];
+                    for (int k = 0; k < 8; ++k) a[r][k] -= fct * a[col][k];
+                }
+        }
+        for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) inv[k * 4 + r] = a[r][4 + k];
+    }
+    const double eye[3] = {c->scene.camera.matrix.t.x, c->scene.camera.matrix.t.y, c->scene.camera.matrix.t.z};
+    // view axis = direction of the central ray
+    double ctr[4];
+    for (int r = 0; r < 4; ++r) ctr[r] = m[12 + r];
+    if (!(std::fabs(ctr[3]) > 1e-300)) return full;
+    double fwd[3] = {ctr[0] / ctr[3] - eye[0], ctr[1] / ctr[3] - eye[1], ctr[2] / ctr[3] - eye[2]};
+    const double fl = std::sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1] + fwd[2] * fwd[2]);
+    if (!(fl > 0.0) || !std::isfinite(fl)) return full;
+    double ext = 0.0;
+    for (int k = 0; k < 3; ++k) { fwd[k] /= fl; ext = std::max(ext, std::fabs((double)root.mx[k] - (double)root.mn[k])); }
+    double px_lo = 1e300, px_hi = -1e300, py_lo = 1e300, py_hi = -1e300;
+    for (int corner = 0; corner < 8; ++corner)
+    {
+        const double X[3] = {corner & 1 ? root.mx[0] : root.mn[0], corner & 2 ? root.mx[1] : root.mn[1], corner & 4 ? root.mx[2] : root.mn[2]};
+        if (!std::isfinite(X[0]) || !std::isfinite(X[1]) || !std::isfinite(X[2])) return full;
+        const double depth = (X[0] - eye[0]) * fwd[0] + (X[1] - eye[1]) * fwd[1] + (X[2] - eye[2]) * fwd[2];
+        if (!(depth > 1e-3 * ext + 1e-6)) return full; // the box reaches (nearly) behind the camera plane: no rectangle bounds its image
+        double q[4];
+        for (int r = 0; r < 4; ++r) q[r] = inv[r] * X[0] + inv[4 + r] * X[1] + inv[8 + r] * X[2] + inv[12 + r];
+        if (!(std::fabs(q[3]) > 1e-300)) return full;
+        const double nx = q[0] / q[3], ny = q[1] / q[3];
+        if (!std::isfinite(nx) || !std::isfinite(ny)) return full;
+        const double px = (nx + 1.0) * 0.5 * W, py = (ny + 1.0) * 0.5 * H; // continuous pixel coordinates: pixel gx spans [gx - 0.5, gx + 0.5]
+        px_lo = std::min(px_lo, px); px_hi = std::max(px_hi, px);
+        py_lo = std::min(py_lo, py); py_hi = std::max(py_hi, py);
+    }
+    const double margin = 3.0;
+    const double gx0 = std::floor(px_lo - 0.5 - margin), gx1 = std::ceil(px_hi + 0.5 + margin) + 1.0;
+    const double gy0 = std::floor(py_lo - 0.5 - margin), gy1 = std::ceil(py_hi + 0.5 + margin) + 1.0;
+    const uint32_t x0 = (uint32_t)std::min<double>(std::max(gx0, 0.0), W), x1 = (uint32_t)std::min<double>(std::max(gx1, 0.0), W);
+    const uint32_t y0 = (uint32_t)std::min<double>(std::max(gy0, 0.0), H), y1 = (uint32_t)std::min<double>(std::max(gy1, 0.0), H);
+    // local rows are in ascending global order: those inside [y0, y1) are contiguous
+    uint32_t ly0 = 0, n = 0;
+    while (ly0 < local_rows && c->rows[ly0] < y0) ++ly0;
+    while (ly0 + n < local_rows && c->rows[ly0 + n] < y1) ++n;
+    return ActiveRect{x0, x1 > x0 ? x1 - x0 : 0u, ly0, n};
+}
+
 int ensure_frame(pt_ctx* c)
 {
     int r;
@@ -495,6 +579,9 @@ int harvest_batch(pt_ctx* c, int pipe)
         }
     }
     c->stats.paths += pp.busy_paths;
+    // camera rays of pixels outside the active rectangle: cast (integrator.rs:179) and answered by the projection of the world's root box
+    c->stats.rays_closest += pp.busy_culled;
+    c->stats.rays_primary_culled += pp.busy_culled;
     c->last_pipe = pipe;
     harvest_events(c, pp);
     return PT_OK;
@@ -517,14 +604,18 @@ int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, boo
     rp.strip_rows = g.strip_rows;
     rp.first_sample = first_sample;
     rp.batch_samples = count;
-    rp.n_paths = c->local_pixels * count;
+    const ActiveRect ar = active_rect(c);
+    rp.act_x0 = ar.x0; rp.act_w = ar.w; rp.act_ly0 = ar.ly0; rp.act_rows = ar.rows;
+    rp.act_pixels = ar.w * ar.rows;
+    rp.n_paths = rp.act_pixels * count;
     rp.max_bounces = g.max_bounces;
     rp.n_sobol = g.n_sobol;
     rp.enable_nee = g.enable_nee;
-    rp.keep_id_from = count >= 2 ? (count - 2) * c->local_pixels : 0u;
-    rp.keep_pos_from = (count - 1) * c->local_pixels;
+    rp.keep_id_from = count >= 2 ? (count - 2) * rp.act_pixels : 0u;
+    rp.keep_pos_from = (count - 1) * rp.act_pixels;
     rp.seed = g.seed;
-    rp.div_local_pixels = fastdiv_make(rp.local_pixels);
+    rp.div_act_pixels = fastdiv_make(rp.act_pixels);
+    rp.div_act_w = fastdiv_make(rp.act_w);
     rp.div_width = fastdiv_make(rp.width);
     rp.div_strip_rows = fastdiv_make(rp.strip_rows);
     const uint32_t rows = g.max_bounces + 2;
@@ -546,8 +637,8 @@ int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, boo
 
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
     HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, s));
-    { Timer t(c, pp, s, T_GEN); launch_generate(s, rp, cam, wb); }
-    const uint32_t shade_blocks = (uint32_t)std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU);
+    if (rp.n_paths) { Timer t(c, pp, s, T_GEN); launch_generate(s, rp, cam, wb); }
+    const uint32_t shade_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU));
     const bool nee = g.enable_nee != 0;
     // The BSDF-sampled NEE launch of a bounce has almost nothing to do since shading answers the rays that miss the lights' root box
     // (it is all launch latency and tail).  It runs on a side stream beside the shadow-ray launch; the main stream waits for it before
@@ -611,19 +702,20 @@ int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, boo
     {
         launch_store_samples(s, rp, wb, samples_out);
         // pt_frame: the frame's own colour goes to the input texture, position / id history are still updated
-        if (aux_with_samples) launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, 1u, 0u);
+        if (aux_with_samples) launch_accumulate(s, rp, cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, 1u, 0u);
     }
     else
     {
         Timer t(c, pp, s, T_ACCUM);
-        launch_accumulate(s, rp, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
+        launch_accumulate(s, rp, cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
     }
     HIPCHK(c, hipEventRecord(pp.ev_done, s));
     HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
     pp.busy = true;
     pp.busy_rows = rows;
-    pp.busy_paths = rp.n_paths;
+    pp.busy_paths = (uint64_t)rp.local_pixels * count;
+    pp.busy_culled = (uint64_t)(rp.local_pixels - rp.act_pixels) * count;
     return PT_OK;
 }
 
@@ -678,31 +770,33 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }
-    uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / c->local_pixels);
+    const ActiveRect ar = active_rect(c);
+    const size_t act_pixels = std::max<size_t>((size_t)ar.w * ar.rows, 1);
+    uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / act_pixels);
     batch = std::min(batch, n_samples);
     uint32_t n_batches = (n_samples + batch - 1) / batch;
     // A request that fits at once but is small (one rank's share of a sharded frame) is still cut in two: its launches are short
     // enough that their tails matter, and two half batches on two pipelines hide them (measured on a 1/8 share of the 1080p x 256 spp
     // frame: -8 %; on the whole frame: +1 %, hence the threshold).
-    if (!c->cfg.batch_spp && n_batches == 1 && want_pipes > 1 && n_samples >= 2 && (uint64_t)n_samples * c->local_pixels <= ((uint64_t)160 << 20))
+    if (!c->cfg.batch_spp && n_batches == 1 && want_pipes > 1 && n_samples >= 2 && (uint64_t)n_samples * act_pixels <= ((uint64_t)40 << 20))
     {
         batch = (n_samples + 1) / 2;
         n_batches = 2;
     }
     uint32_t n_pipes = std::min(want_pipes, n_batches);
-    if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * c->local_pixels * n_pipes > max_paths)
+    if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * act_pixels * n_pipes > max_paths)
     {
         // the request does not fit at once: the pipelines share the memory
-        batch = (uint32_t)std::max<size_t>(1, max_paths / n_pipes / c->local_pixels);
+        batch = (uint32_t)std::max<size_t>(1, max_paths / n_pipes / act_pixels);
         n_batches = (n_samples + batch - 1) / batch;
     }
     batch = (n_samples + n_batches - 1) / n_batches;
-    if ((uint64_t)batch * c->local_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
+    if ((uint64_t)batch * act_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
     // pipelines this call does not use give their memory back
     for (int i = (int)n_pipes; i < pt_ctx::kMaxPipes; ++i)
         if (!c->pipe[i].busy && c->pipe[i].cap_paths) free_pipe_pool(c->pipe[i]);
     for (uint32_t i = 0; i < n_pipes; ++i)
-        if ((r = ensure_wavefront(c, (int)i, (size_t)batch * c->local_pixels, c->cfg.max_bounces + 2))) return r;
+        if ((r = ensure_wavefront(c, (int)i, (size_t)batch * act_pixels, c->cfg.max_bounces + 2))) return r;
     DevBuf d_samples;
     if (samples_out && (r = dev_alloc(c, d_samples, (size_t)batch * c->local_pixels * 16))) return r;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1682,7 +1776,7 @@ int pt_multi_get_stats(pt_multi* m, pt_stats* sum)
     {
         const pt_stats& s = c->stats;
         sum->rays_closest += s.rays_closest; sum->rays_any += s.rays_any; sum->rays_light_closest += s.rays_light_closest;
-        sum->rays_light_closest_traced += s.rays_light_closest_traced; sum->paths += s.paths;
+        sum->rays_light_closest_traced += s.rays_light_closest_traced; sum->rays_primary_culled += s.rays_primary_culled; sum->paths += s.paths;
         sum->launches_trace_closest += s.launches_trace_closest; sum->ms_trace_closest += s.ms_trace_closest;
         sum->ms_trace_any += s.ms_trace_any; sum->ms_trace_light += s.ms_trace_light; sum->ms_shade += s.ms_shade;
         sum->ms_generate += s.ms_generate; sum->ms_accumulate += s.ms_accumulate;

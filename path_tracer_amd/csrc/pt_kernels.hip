@@ -31,6 +31,13 @@ namespace {
 #ifndef PT_STEPS_ANY
 #define PT_STEPS_ANY PT_STEPS_PER_ROUND
 #endif
+// waves per SIMD the compiler must leave room for in the traversal kernels that read the BVH from global memory (they wait on L2)
+#ifndef PT_WAVES_GLOBAL_BVH
+#define PT_WAVES_GLOBAL_BVH 4
+#endif
+#ifndef PT_WAVES_GLOBAL_BVH_ANY
+#define PT_WAVES_GLOBAL_BVH_ANY 4
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -531,7 +538,7 @@ struct Stack8<true>
 
 // ------------------------------------------------------------------------------------------------ closest hit
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+__global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                                   const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                                   uint32_t* __restrict__ heads, const ClosestOut out)
 {
@@ -927,7 +934,7 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 // tested when its parent is expanded (the instance's BLAS root right after the ray transform) and only nodes that were hit go
 // on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+__global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                               uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                               f4* __restrict__ radiance)
@@ -1090,26 +1097,23 @@ __device__ __forceinline__ uint32_t global_row(const RenderParams& rp, uint32_t 
 }
 __device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t pid)
 {
-    const uint32_t s = fastdiv(pid, rp.div_local_pixels), lp = pid - s * rp.local_pixels;
-    const uint32_t ly = fastdiv(lp, rp.div_width), x = lp - ly * rp.width;
+    const uint32_t s = fastdiv(pid, rp.div_act_pixels), k = pid - s * rp.act_pixels;
+    const uint32_t r = fastdiv(k, rp.div_act_w), x = rp.act_x0 + (k - r * rp.act_w);
+    const uint32_t ly = rp.act_ly0 + r;
     const uint32_t gy = global_row(rp, ly);
-    return PixelId{gy * rp.width + x, rp.first_sample + s, lp, x, gy};
+    return PixelId{gy * rp.width + x, rp.first_sample + s, ly * rp.width + x, x, gy};
 }
 
-// main.rs:186-199
-__global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const CameraView cam, const RayQueue rq, Counters* ctr)
+// direction of the camera ray of (pixel gx, gy; sample): main.rs:193-199 + Camera::create_ray camera.rs:94-105
+__device__ __forceinline__ f3 camera_ray_dir(const RenderParams& rp, const CameraView& cam, uint32_t gx, uint32_t gy, uint32_t sample)
 {
-    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid == 0u) ctr[0].n_closest = rp.n_paths;
-    if (pid >= rp.n_paths) return;
-    const PixelId px = path_pixel(rp, pid);
-    Stream rng{stream_key(rp.seed, px.gpixel, px.sample), 0u};
+    Stream rng{stream_key(rp.seed, gy * rp.width + gx, sample), 0u};
     const uint32_t seed = rng.u32();                                       // main.rs:193 (the stream's draw 0)
     float jx, jy;
-    ss_sobol(rp.n_sobol, px.sample, seed, &jx, &jy);                       // main.rs:194
+    ss_sobol(rp.n_sobol, sample, seed, &jx, &jy);                          // main.rs:194
     const float ox = jx - 0.5f, oy = jy - 0.5f;
-    const float u = ((float)px.gx + ox) / (float)rp.width;                 // main.rs:196
-    const float v = ((float)px.gy + oy) / (float)rp.height;                // main.rs:197
+    const float u = ((float)gx + ox) / (float)rp.width;                    // main.rs:196
+    const float v = ((float)gy + oy) / (float)rp.height;                   // main.rs:197
     // Camera::create_ray  camera.rs:94-105  (Mat4::project_point3, then normalise)
     const float nx = u * 2.0f - 1.0f, ny = v * 2.0f - 1.0f, nz = 0.0f;
     const float* M = cam.ray_matrix;
@@ -1125,7 +1129,17 @@ __global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const C
     }
     const float rw = 1.0f / r[3];
     const f3 eye{cam.eye[0], cam.eye[1], cam.eye[2]};
-    const f3 dir = unit3(f3{r[0] * rw, r[1] * rw, r[2] * rw} - eye);
+    return unit3(f3{r[0] * rw, r[1] * rw, r[2] * rw} - eye);
+}
+
+// main.rs:186-199
+__global__ void __launch_bounds__(256) k_generate(const RenderParams rp, const CameraView cam, const RayQueue rq, Counters* ctr)
+{
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid == 0u) ctr[0].n_closest = rp.n_paths;
+    if (pid >= rp.n_paths) return;
+    const PixelId px = path_pixel(rp, pid);
+    const f3 dir = camera_ray_dir(rp, cam, px.gx, px.gy, px.sample);
     rq.b[pid] = f4{dir.x, dir.y, dir.z, asf(pid)};
     // no state is initialised: bounce 0 knows path_weight = 1, accumulated = 0, one draw consumed (integrator.rs:153-161)
 }
@@ -1588,14 +1602,32 @@ __device__ __forceinline__ f3 finalise(f3 acc)
     return clamp_len_max(acc, 100.0f);
 }
 
-// accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206
-__global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const PathState st, f4* accum, f4* position, uint32_t* id,
+// accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206.  One thread per LOCAL pixel; a pixel
+// outside the active rectangle (RenderParams::act_*) never had a path: each of its samples is the miss result of integrator.rs:263-266
+// — radiance 0.006, id 255, position r.at(1e5) of that sample's camera ray (:156-157) — added sample by sample like any other.
+__global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const CameraView cam, const PathState st, f4* accum, f4* position, uint32_t* id,
                                                      const uint32_t write_position, const uint32_t add_to_accum)
 {
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= rp.local_pixels) return;
     f4 a = accum[lp];
     uint32_t idv = id[lp];
+    const uint32_t ly = fastdiv(lp, rp.div_width), x = lp - ly * rp.width;
+    if (x - rp.act_x0 >= rp.act_w || ly - rp.act_ly0 >= rp.act_rows)
+    {
+        for (uint32_t s = 0; s < rp.batch_samples; ++s) a = f4{a.x + 0.006f, a.y + 0.006f, a.z + 0.006f, a.w + 1.0f};
+        for (uint32_t s = rp.batch_samples >= 2u ? rp.batch_samples - 2u : 0u; s < rp.batch_samples; ++s) idv = (idv << 16) | 255u;
+        if (add_to_accum) accum[lp] = a;
+        id[lp] = idv;
+        if (write_position)
+        {
+            const f3 d = camera_ray_dir(rp, cam, x, global_row(rp, ly), rp.first_sample + rp.batch_samples - 1u);
+            const f3 far = fma3(d, bc3(1e5f), f3{cam.eye[0], cam.eye[1], cam.eye[2]});
+            position[lp] = f4{far.x, far.y, far.z, 1e5f};
+        }
+        return;
+    }
+    const uint32_t k = (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0);
     // eight samples' loads in flight at a time (the sum must be taken in sample order, the loads need not wait for each other)
     constexpr uint32_t G = 8;
     for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += G)
@@ -1603,14 +1635,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
         uint32_t oc[G];
         f4 rad[G];
 #pragma unroll
-        for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.local_pixels + lp] : (uint32_t)PRIMARY_MISS;
+        for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
 #pragma unroll
-        for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.local_pixels + lp] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+        for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
 #pragma unroll
         for (uint32_t j = 0; j < G; ++j)
         {
             if ((s0 + j) >= rp.batch_samples) break;
-            const uint32_t pid = (s0 + j) * rp.local_pixels + lp;
+            const uint32_t pid = (s0 + j) * rp.act_pixels + k;
             const f3 c = finalise(xyz(rad[j]));
             a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
             // (id << 16) | new once per sample: only the last two samples survive in 32 bits
@@ -1619,15 +1651,23 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
     }
     if (add_to_accum) accum[lp] = a;
     id[lp] = idv;
-    if (write_position) position[lp] = st.first_pos[lp]; // the batch's last sample: (batch_samples - 1) * local_pixels + lp - keep_pos_from
+    if (write_position) position[lp] = st.first_pos[k]; // the batch's last sample: (batch_samples - 1) * act_pixels + k - keep_pos_from
 }
 
+// per-sample radiance (pt_render_samples): out[sample * local_pixels + local pixel]
 __global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, const PathState st, f4* out)
 {
-    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid >= rp.n_paths) return;
-    const f3 c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
-    out[pid] = f4{c.x, c.y, c.z, 1.0f};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.local_pixels * rp.batch_samples) return;
+    const uint32_t s = i / rp.local_pixels, lp = i - s * rp.local_pixels;
+    const uint32_t ly = fastdiv(lp, rp.div_width), x = lp - ly * rp.width;
+    f3 c{0.006f, 0.006f, 0.006f};
+    if (x - rp.act_x0 < rp.act_w && ly - rp.act_ly0 < rp.act_rows)
+    {
+        const uint32_t pid = s * rp.act_pixels + (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0);
+        c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
+    }
+    out[i] = f4{c.x, c.y, c.z, 1.0f};
 }
 
 // ------------------------------------------------------------------------------------------------ probes
@@ -1859,15 +1899,15 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     }
 }
 
-void launch_accumulate(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
+void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
                        uint32_t write_position, uint32_t add_to_accum)
 {
     const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, wb.st, accum, position, id, write_position, add_to_accum);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
 }
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)
 {
-    const uint32_t blocks = (rp.n_paths + 255u) / 256u;
+    const uint32_t blocks = (uint32_t)(((uint64_t)rp.local_pixels * rp.batch_samples + 255u) / 256u);
     hipLaunchKernelGGL(k_store_samples, dim3(blocks), dim3(256), 0, s, rp, wb.st, out);
 }
 

@@ -164,13 +164,18 @@ struct RenderParams
     uint32_t rank, world_size, strip_rows;
     uint32_t first_sample;   // global index of batch-local sample 0
     uint32_t batch_samples;
-    uint32_t n_paths;        // local_pixels * batch_samples
+    uint32_t n_paths;        // act_pixels * batch_samples
     uint32_t max_bounces, n_sobol, enable_nee;
     uint32_t keep_id_from;   // path ids >= this belong to the batch's last two samples (id history, main.rs:206)
     uint32_t keep_pos_from;  // path ids >= this belong to the batch's last sample (first-hit position, main.rs:205)
-    uint32_t pad;
+    // Camera rays are generated only for the ACTIVE pixels: a rectangle of columns [act_x0, act_x0 + act_w) and LOCAL rows
+    // [act_ly0, act_ly0 + act_rows) outside which every camera ray provably misses the scene's bounds (the host projects the world
+    // TLAS's root box onto the image plane, with a margin; pt_api.cpp).  Path id = sample * act_pixels + (row - act_ly0) * act_w +
+    // (column - act_x0); pixels outside the rectangle get the miss result (integrator.rs:263-266) in k_accumulate.
+    uint32_t act_x0, act_w, act_ly0, act_rows, act_pixels;
+    uint32_t pad[2];
     uint64_t seed;
-    FastDiv div_local_pixels, div_width, div_strip_rows;
+    FastDiv div_act_pixels, div_act_w, div_width, div_strip_rows;
 };
 
 // wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel).  What a shading pass reads and writes together is

@@ -509,6 +509,40 @@ def test_framebuffer_is_visible_to_torch_in_place(api, cornell64):
     r.set_stream(None)
 
 
+@pytest.mark.parametrize("eye,target,fov,culls", [
+    ((0.0, 50.0, 1000.0), (0.0, 50.0, 0.0), 60.0, True),      # the reference camera: the room fills a third of the frame
+    ((900.0, 700.0, 1100.0), (0.0, 0.0, 0.0), 35.0, True),    # from a corner: the box's image is a hexagon
+    ((0.0, 50.0, 1000.0), (900.0, 50.0, 0.0), 40.0, True),    # the room half out of the frame
+    ((0.0, 50.0, 1000.0), (0.0, 420.0, 0.0), 20.0, True),     # the room entirely out of the (narrow) frame: no path at all
+    ((0.0, 50.0, 1000.0), (0.0, 3000.0, 0.0), 30.0, False),   # looking past it steeply: part of the box is behind the image plane, no rectangle bounds it
+    ((0.0, 50.0, 100.0), (0.0, 50.0, 0.0), 60.0, False)])     # inside the room: nothing can be culled
+def test_camera_rays_outside_the_scene_bounds_are_not_generated(api, oracle_mod, eye, target, fov, culls):
+    """Pixels whose every camera ray misses the world's root box (the host projects the box onto the image plane) get the miss result
+    without a path.  Same frame, positions, ids and ray tallies as with PT_FLAG_NO_PRIMARY_CULL and as the oracle, whatever the view;
+    sharded rows included."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.dist import rows_of_rank
+    from path_tracer_amd.scene_desc import Camera, SceneDesc
+    W, H = 160, 90
+    sc = SceneDesc.new(scenes.cornell_models(), Camera.new(eye, target, fov, W / H), "view")
+    a = api.Renderer(sc, W, H, max_bounces=5)
+    b = api.Renderer(sc, W, H, max_bounces=5, flags=api.FLAG_NO_PRIMARY_CULL)
+    ra, rb = a.render(2, 3), b.render(2, 3)
+    for x, y, what in zip(ra, rb, ("accumulation", "position", "id")):
+        assert_bit_equal(x, y, f"culled vs not: {what}")
+    sa, sb = a.stats(), b.stats()
+    assert (sa.rays_closest, sa.rays_any, sa.rays_light_closest, sa.paths) == (sb.rays_closest, sb.rays_any, sb.rays_light_closest, sb.paths)
+    assert sb.rays_primary_culled == 0 and (sa.rays_primary_culled > 0) == culls
+    o = oracle_mod.Oracle(sc).render(W, H, 3, first_sample=2, max_bounces=5)
+    assert_bit_equal(ra[0], o[0], "vs oracle"); assert_bit_equal(ra[1], o[1], "position vs oracle"); assert np.array_equal(ra[2], o[2])
+    assert_bit_equal(a.render_samples(0, 2), b.render_samples(0, 2), "per-sample radiance")
+    full = np.zeros_like(rb[1])
+    for rank in range(3):
+        rr = api.Renderer(sc, W, H, max_bounces=5, rank=rank, world_size=3, strip_rows=4)
+        full[rows_of_rank(H, rank, 3, 4)] = rr.render(2, 3)[1]
+    assert_bit_equal(full, rb[1], "first-hit positions of three ranks' strips")
+
+
 def test_multi_device_context_through_the_c_abi(api, oracle_mod):
     """pt_multi: one process driving N contexts.  (a) one device through RCCL (a one-rank communicator; ncclGather to itself),
     (b) three contexts SHARING the device: strips of every rank gathered by device copies and de-interleaved on the GPU.  Both must

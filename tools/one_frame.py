@@ -9,10 +9,11 @@ name = sys.argv[3] if len(sys.argv) > 3 else "cornell_box"
 spp = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 kw = {}
 pipes = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+stack_lds = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 if ":" in name:
     name, lv = name.split(":"); kw["level"] = int(lv)
 W, H = 1920, 1080
-r = api.Renderer(getattr(scenes, name)(W, H, **kw), W, H, max_bounces=8, rank=0, world_size=world, strip_rows=4, batch_spp=batch, pipelines=pipes)
+r = api.Renderer(getattr(scenes, name)(W, H, **kw), W, H, max_bounces=8, rank=0, world_size=world, strip_rows=4, batch_spp=batch, pipelines=pipes, stack_lds_levels=stack_lds)
 r.render_device(0, spp); r.synchronize()
 r.reset_accumulation(); r.reset_stats()
 import time

@@ -45,15 +45,22 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"Cornell {WIDTH}x{HEIGHT}, {spp} spp of 256, depth {DEPTH}, {threads} threads, {dt:.1f} s"}
 
 
-def _profiled_traffic(rays_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
-    separate passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect PMC
-    counters on itself: the profiled bytes PER RAY (same kernel, same scene) are scaled by this run's rays per launch."""
+PROFILE_TAG = "r02"             # profiles/<tag>_traffic.json: the committed rocprofv3 PMC passes the counter-derived fields come from
+
+
+def _profiled(rays_per_launch):
+    """Counter-derived fields of the dominant kernel from the committed rocprofv3 PMC passes of THIS round (explicit tag, not "the
+    newest file"): HBM bytes (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md), VALU-active share of wave lifetime and lanes active per VALU instruction.  bench.py cannot collect PMC
+    counters on itself: the profiled bytes PER RAY (same kernel, same scene) are scaled by this run's rays per launch, and the
+    provenance is stated in the record."""
     try:
-        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-        k = json.load(open(os.path.join(ROOT, "profiles", files[-1])))["k_closest_world"]
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_ray"] * rays_per_launch,
-                "source": f"profiles/{files[-1]}: {k['hbm_bytes_per_ray']:.1f} B/ray measured over {k['rays'] / 1e6:.0f} M rays x this run's rays per launch"}
+        name = f"{PROFILE_TAG}_traffic.json"
+        k = json.load(open(os.path.join(ROOT, "profiles", name)))["k_closest_world"]
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_ray"] * rays_per_launch, "valu_active_frac": k.get("valu_active_frac"),
+                "lanes_per_valu_instr": k.get("lanes_per_valu_instr"),
+                "source": f"profiles/{name} (rocprofv3 --pmc passes of `bench.py --steps 1 --spp {k.get('spp', 43)}`, committed with this round): "
+                          f"{k['hbm_bytes_per_ray']:.1f} B/ray over {k['rays'] / 1e6:.0f} M rays, scaled by this run's rays per launch"}
     except Exception:
         return None
 
@@ -66,7 +73,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--batch-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every launch (diagnostic, slower)")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every launch INSIDE the timed region (diagnostic, slower)")
     args = ap.parse_args()
 
     import torch
@@ -122,29 +129,56 @@ def main():
     else:
         rays, paths = float(st.rays), float(st.paths)
 
+    kernel_ms = None
+    if rank == 0 and world == 1:
+        # every kernel category timed, in a SECOND, untimed step (HIP events around every launch serialise the side stream and add
+        # idle time, so they stay out of the timed region)
+        r.set_config(flags=api.FLAG_TIMING_ALL)
+        r.reset_stats()
+        step()
+        torch.cuda.synchronize(dev)
+        s2 = r.stats()
+        kernel_ms = {"trace_closest": s2.ms_trace_closest, "trace_any": s2.ms_trace_any, "trace_light": s2.ms_trace_light, "shade": s2.ms_shade,
+                     "generate": s2.ms_generate, "accumulate": s2.ms_accumulate,
+                     "source": "one extra untimed step with HIP events around every launch (PT_FLAG_TIMING_ALL); per step"}
+
     if rank == 0:
         launches = max(1, st.launches_trace_closest)
         avg_ms = st.ms_trace_closest / launches
-        bytes_per_launch = BYTES_PER_CLOSEST_RAY * st.rays_closest / launches
+        traced_closest = st.rays_closest - st.rays_primary_culled       # camera rays answered by the projection never reach the kernel
+        bytes_per_launch = BYTES_PER_CLOSEST_RAY * traced_closest / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traversed = traced_closest + st.rays_any + st.rays_light_closest_traced
         out = {
             "metric": "Mray/s at 1920x1080, 256 spp; achieved HBM GB/s in traversal kernel",
             "value": rays / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell box (36 triangles, 6 BLAS) {WIDTH}x{HEIGHT}, {args.spp} spp, depth {DEPTH}, NEE+MIS",
-                       "parallelism": f"rows/{world}", "mpaths_per_s": paths / dt / 1e6, "rays_per_path": rays / max(paths, 1.0)},
+                       "parallelism": f"rows/{world}", "mpaths_per_s": paths / dt / 1e6, "rays_per_path": rays / max(paths, 1.0),
+                       # `value` counts casts at the reference's call sites (integrator.rs:179,56,100,103), which is also how the CPU
+                       # baseline counts.  Not every cast is a traversal: per step, rank 0
+                       "rays_by_class": {"closest_traversed": traced_closest // args.steps,
+                                         "closest_camera_rays_culled_by_projection": st.rays_primary_culled // args.steps,
+                                         "any_traversed": st.rays_any // args.steps,
+                                         "light_closest_traversed": st.rays_light_closest_traced // args.steps,
+                                         "light_closest_culled_in_shade": (st.rays_light_closest - st.rays_light_closest_traced) // args.steps},
+                       "traversed_Mray_per_s": (traversed / dt / 1e6) if world == 1 else None,
+                       "state_GiB": st.state_bytes / 2 ** 30},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_closest<LDS, PRIMARY|WORLD>", "avg_launch_ms": avg_ms, "launches": int(launches),
-                         "algorithmic_bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": st.rays_closest / launches,
-                         "closest_Mray_per_s_in_kernel": st.rays_closest / max(st.ms_trace_closest, 1e-9) / 1e3},
-            "kernel_ms": {"trace_closest": st.ms_trace_closest, "trace_any": st.ms_trace_any, "trace_light": st.ms_trace_light,
-                          "shade": st.ms_shade, "generate": st.ms_generate, "accumulate": st.ms_accumulate},
+                         "algorithmic_bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": traced_closest / launches,
+                         "closest_Mray_per_s_in_kernel": traced_closest / max(st.ms_trace_closest, 1e-9) / 1e3,
+                         "valu_active_frac": None, "lanes_per_valu_instr": None,
+                         "note": "the 36-triangle BVH is LDS-resident: the kernel is bound by VALU issue at low lane utilisation, not by HBM (DESIGN.md 4)"},
+            "kernel_ms": kernel_ms,
         }
-        tr = _profiled_traffic(st.rays_closest / launches)
+        tr = _profiled(traced_closest / launches)
         if tr is not None:
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
+            out["roofline"]["valu_active_frac"] = tr["valu_active_frac"]
+            out["roofline"]["lanes_per_valu_instr"] = tr["lanes_per_valu_instr"]
+            out["roofline"]["counters_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

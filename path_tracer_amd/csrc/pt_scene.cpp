@@ -226,6 +226,12 @@ int HostScene::add_material(int kind, const float colour[3], float roughness, fl
 int HostScene::add_model(const float* positions, const float* normals, uint32_t n_tris, int material, const float* affines, uint32_t n_inst)
 {
     if (!positions || !normals || n_tris == 0 || material < 0 || material >= (int)materials.size() || (n_inst && !affines)) return -1;
+    // Vertex positions must be numbers: a NaN or infinite coordinate makes every box it touches NaN / infinite, the builders'
+    // surface-area comparisons (tlas_bvh.rs:56-83, blas_bvh.rs:93-110) then have no minimum — the reference's `min_by(partial_cmp)
+    // .unwrap()` panics — and no traversal could return anything meaningful.  (Found by the host sanitizer build: the TLAS builder
+    // indexed its work list with "no partner".)
+    for (size_t i = 0; i < (size_t)n_tris * 9; ++i)
+        if (!finite_f(positions[i])) return -1;
     HostModel m;
     m.n_tris = n_tris;
     m.material = material;
@@ -313,6 +319,7 @@ int HostScene::add_model_obj(const char* path, int material, const float* affine
         {
             f3 v;
             if (tok.size() < 4 || !parse_f32(tok[1], &v.x) || !parse_f32(tok[2], &v.y) || !parse_f32(tok[3], &v.z)) return bad("expected three numbers");
+            if (tok[0] == "v" && (!finite_f(v.x) || !finite_f(v.y) || !finite_f(v.z))) return bad("vertex coordinate is not a finite number");
             if (tok[0] == "v") positions.push_back(v);
             else normals.push_back(unit3(v));                                                  // blas.rs:74
         }
@@ -399,6 +406,7 @@ void HostScene::build_tlas(HostTlas& out, const std::vector<uint32_t>& model_ids
             const float sa = box_area(box_join(out.nodes[open[self]].box, out.nodes[open[i]].box));
             if (sa < best) { best = sa; idx = i; }
         }
+        if (idx == SIZE_MAX) idx = self == 0 ? 1 : 0; // every joined area is infinite (boxes ~1e19 apart overflow binary32): any partner
         return idx;
     };
     auto take = [&](size_t i) { uint32_t v = open[i]; open[i] = open.back(); open.pop_back(); return v; }; // Vec::swap_remove

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o r1 -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$O/kt.log" 2>&1
 echo "kernel trace done"
 i=1
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU" \
            "FETCH_SIZE" \
            "WRITE_SIZE" \

@@ -41,7 +41,7 @@ def main(src, tag):
         lines += ["", "## PMC passes (`--pmc`, one pass per counter group; bench.py --steps 1 --warmup 0 --spp 43)", "",
                   "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                   "(MI355X_MICROARCH.md §HBM), so read bytes below = 2 x FETCH_SIZE x 1024.", ""]
-        cols = [c for c in ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+        cols = [c for c in ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
                             "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"] if c in g.columns]
         lines += ["| kernel | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
         for k, r in g.iterrows():
@@ -65,11 +65,17 @@ def main(src, tag):
                 for ln in open(os.path.join(src, name)):
                     if ln.startswith("{"):
                         bench = json.loads(ln)
-        rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]
+        rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]  # rays that reached the kernel in the profiled (timed) step
         keys = [k for k in traffic if re.match(r"k_closest<\w+, [03](, \w+)?>$", k)]
         tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
-        traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays,
-                                      "note": "PMC passes at batch 43 spp; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read"}
+        va = sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) / sum(g.loc[k, "SQ_WAVE_CYCLES"] for k in keys) if "SQ_WAVE_CYCLES" in g.columns else None
+        ln = sum(g.loc[k, "SQ_THREAD_CYCLES_VALU"] for k in keys) / sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) if "SQ_THREAD_CYCLES_VALU" in g.columns else None
+        traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays, "spp": bench["config"]["workload"].split(" spp")[0].split(", ")[-1],
+                                      "valu_active_frac": va, "lanes_per_valu_instr": ln,
+                                      "note": "PMC passes at batch 43 spp; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read; valu_active_frac = "
+                                              "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's lifetime it issues VALU; x resident waves per SIMD = VALU busy), "
+                                              "lanes_per_valu_instr = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
+        if va is not None: lines += ["", f"k_closest PRIMARY+WORLD: VALU-active share of wave lifetime {va:.3f}; lanes active per VALU instruction {ln if ln is None else round(ln, 1)} of 64."]
         lines += ["", f"Dominant kernel (k_closest, modes PRIMARY+WORLD): {tot / 1e9:.2f} GB of HBM traffic for {rays / 1e6:.1f} M rays = "
                   f"**{tot / rays:.1f} B/ray** (algorithmic: 48 B/ray)."]
     except Exception as e:  # noqa: BLE001

@@ -248,6 +248,10 @@ int pt_multi_get_stats(pt_multi* m, pt_stats* sum);   /* counters summed over th
  * [4] NEE-chain slots, [6] NEE-chain rays traced, [7] of those hitting a light, [8..12] shade-queue slots (terminal, lambert,
  * specular, dielectric, ggx), [13] closest rays traced, [14] shadow rays traced.  Slots include the holes producers return. */
 int pt_last_batch_counters(pt_ctx* ctx, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows);
+/* diagnostic, meaningful only with a -DPT_STEP_STATS=1 build of the kernels (tools/step_stats.py): per bounce, 8 words: traversal
+ * wave-steps of the world closest-hit kernel, lanes active in them, lanes taking the instance / branch / triangle-leaf section, wave-steps
+ * in which some lane took the instance / branch / leaf section */
+int pt_last_batch_step_stats(pt_ctx* ctx, uint32_t* rows8, uint32_t cap_rows, uint32_t* n_rows);
 int pt_reset_stats(pt_ctx* ctx);
 
 #ifdef __cplusplus

@@ -32,7 +32,7 @@ EXPORTS = [
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
-    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters",
+    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_step_stats",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
     "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl", "pt_multi_write_image",
 ]
@@ -477,6 +477,12 @@ class Renderer:
         rows = np.zeros((self.cfg.max_bounces + 2, 16), np.uint32)
         n = C.c_uint32()
         self._chk(self.L.pt_last_batch_counters(self.ctx, _p(rows), rows.shape[0], C.byref(n)))
+        return rows[: n.value]
+
+    def last_batch_step_stats(self):
+        rows = np.zeros((self.cfg.max_bounces + 2, 8), np.uint32)
+        n = C.c_uint32()
+        self._chk(self.L.pt_last_batch_step_stats(self.ctx, _p(rows), rows.shape[0], C.byref(n)))
         return rows[: n.value]
 
     def reset_stats(self):

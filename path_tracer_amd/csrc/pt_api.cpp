@@ -1819,6 +1819,26 @@ int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint3
     return PT_OK;
 }
 
+// diagnostic (PT_STEP_STATS variant builds, tools/step_stats.py): words 8..15 of the closest-hit cursor lines of the last batch, summed
+// over the 64 lines, one row of 8 words per bounce
+int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint32_t* n_rows)
+{
+    if (!c || !rows8 || !n_rows) return PT_ERR_ARG;
+    const pt_ctx::Pipe& pp = c->pipe[c->last_pipe];
+    if (!pp.h_heads) return PT_ERR_STATE;
+    const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
+    for (uint32_t r = 0; r < rows; ++r)
+    {
+        uint32_t* o = rows8 + 8 * r;
+        std::memset(o, 0, 32);
+        const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue + HEADS_CLOSEST * kHeadWordsPerQueue;
+        for (uint32_t g = 0; g < kQueueHeads; ++g)
+            for (uint32_t k = 0; k < 8; ++k) o[k] += hrow[g * kHeadStrideWords + 8 + k];
+    }
+    *n_rows = rows;
+    return PT_OK;
+}
+
 int pt_reset_stats(pt_ctx* c)
 {
     if (!c) return PT_ERR_ARG;

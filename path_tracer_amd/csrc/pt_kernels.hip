@@ -38,6 +38,17 @@ namespace {
 #ifndef PT_WAVES_GLOBAL_BVH_ANY
 #define PT_WAVES_GLOBAL_BVH_ANY 4
 #endif
+// branch levels expanded per traversal step of k_closest (1 = one node per step)
+#ifndef PT_BRANCH_LEVELS
+#define PT_BRANCH_LEVELS 4
+#endif
+#ifndef PT_BRANCH_LEVELS_ANY
+#define PT_BRANCH_LEVELS_ANY 4
+#endif
+// PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
+#ifndef PT_STEP_STATS
+#define PT_STEP_STATS 0
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -564,6 +575,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
     // material binning (CLOSEST_WORLD / PRIMARY): a retiring ray's hit record goes straight to its class's shade queue, into a region
     // of that queue this wave has reserved (wave_reserve: one atomic per region, none per entry)
     uint32_t light_hits = 0, valid_rays = 0;
+#if PT_STEP_STATS
+    uint32_t st_iter = 0, st_lane_active = 0, st_lane_inst = 0, st_lane_branch = 0, st_lane_leaf = 0, st_wave_inst = 0, st_wave_branch = 0, st_wave_leaf = 0;
+#endif
     Region bin_region[Q_COUNT];
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
@@ -757,6 +771,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
 #pragma unroll 1
         for (int it = 0; it < kStepsPerRound; ++it)
         {
+#if PT_STEP_STATS
+            {
+                const uint64_t am = __ballot(active);
+                if (am != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(am); }
+            }
+#endif
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
             if (MODE == CLOSEST_LIGHTS && any_phase)
@@ -834,6 +854,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
             if (asf(e.y) > t_max) continue;                  // tlas.rs:80-83 / blas.rs:222-225
             uint32_t link = e.x;
             float t_est = asf(e.y);
+#if PT_STEP_STATS
+            { const bool x = (link >> NODE_KIND_SHIFT) == NODE_INSTANCE; const uint64_t m = __ballot(x); st_lane_inst += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_inst += 1u; }
+#endif
             if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
             {
                 // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99.  BLAS::intersect pushes its root
@@ -848,10 +871,17 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                 t_est = 0.0f;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
-            if (kind == NODE_BRANCH)
+#if PT_STEP_STATS
+            { const bool x = kind == NODE_BRANCH; const uint64_t m = __ballot(x); st_lane_branch += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_branch += 1u; }
+#endif
+            // push_to_stack  blas.rs:133-162.  A near child that is itself a branch is expanded in the SAME step (up to PT_BRANCH_LEVELS
+            // levels) instead of going through the stack: the kernel pays per wave-step far more than per section of a step
+            // (profiles/r02_step_stats_cornell.md), and the reference would pop exactly that child next (its pop test t_enter > t_max
+            // cannot fire: the box was just met within t_max).
+#pragma unroll 1
+            for (int lvl = 0; lvl < PT_BRANCH_LEVELS && kind == NODE_BRANCH; ++lvl)
             {
-                // push_to_stack  blas.rs:133-162; the children are one contiguous 64-byte record pair
-                const uint4* cp = bl.nodes + 2u * payload;
+                const uint4* cp = bl.nodes + 2u * payload; // the children are one contiguous 64-byte record pair
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
@@ -861,20 +891,25 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                 const bool left_near = tl < tr;
                 const uint2 le = make_uint2(l0.w, asu(tl)), re = make_uint2(r0.w, asu(tr));
                 if (hl && hr) { stk.put(sp, left_near ? re : le); sp = stk.up(sp); }
+                kind = NODE_INSTANCE; // nothing more to do in this step unless the near child says otherwise
                 if (hl || hr)
                 {
-                    // the entry the reference pops next.  A triangle leaf is dealt with in this very step (its pop test t_enter > t_max
-                    // cannot fire: the box was just met within t_max); anything else goes on the stack
+                    // the entry the reference pops next.  A triangle leaf is dealt with in this very step, a branch in the next level of
+                    // this loop; an instance (or a branch beyond the last level) goes on the stack
                     const uint2 near = (hl && (left_near || !hr)) ? le : re;
-                    if ((near.x >> NODE_KIND_SHIFT) & 1u) // NODE_TRIS or NODE_TRIS_BIG
+                    const uint32_t nk = near.x >> NODE_KIND_SHIFT;
+                    if ((nk & 1u) != 0u || (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS))
                     {
-                        kind = near.x >> NODE_KIND_SHIFT;
+                        kind = nk;
                         payload = near.x & NODE_PAYLOAD_MASK;
                         t_est = asf(near.y);
                     }
                     else { stk.put(sp, near); sp = stk.up(sp); }
                 }
             }
+#if PT_STEP_STATS
+            { const bool x = (kind & 1u) != 0u; const uint64_t m = __ballot(x); st_lane_leaf += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_leaf += 1u; }
+#endif
             if (kind & 1u)
             {
                 uint32_t first, count;
@@ -920,6 +955,21 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
             for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
         }
     }
+#if PT_STEP_STATS
+    // words 8..15 of the cursor lines: wave-steps executed, lanes active in them, lanes taking the instance / branch / leaf section, and
+    // (words 13..15) wave-steps in which at least one lane took that section; tools/step_stats.py reads these.
+    {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        if (lane_id() == 0u) { atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); }
+        uint32_t a = st_lane_inst, b = st_lane_branch, c2 = st_lane_leaf;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c2 += __shfl_xor(c2, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 10, a); atomicAdd(line + 11, b); atomicAdd(line + 12, c2); }
+        a = st_wave_inst; b = st_wave_branch; c2 = st_wave_leaf;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c2 += __shfl_xor(c2, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 13, a); atomicAdd(line + 14, b); atomicAdd(line + 15, c2); }
+    }
+#endif
     if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
     // any-hit casts of integrator.rs:103
     if (MODE == CLOSEST_LIGHTS) add_tally(heads, light_hits, HEAD_TALLY1);
@@ -1048,8 +1098,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
                 if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
                 link = r0.w;
             }
-            const uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
-            if (kind == NODE_BRANCH)
+            uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+            // up to PT_BRANCH_LEVELS_ANY levels per step: the child that would be popped next (right if met, else left) is expanded or
+            // tested at once instead of going through the stack (the kernel pays per wave-step, profiles/r02_step_stats_cornell.md)
+#pragma unroll 1
+            for (int lvl = 0; lvl < PT_BRANCH_LEVELS_ANY && kind == NODE_BRANCH; ++lvl)
             {
                 const uint4* cp = bl.nodes + 2u * payload;
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
@@ -1057,10 +1110,22 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);
                 const bool hr = slab(r0, r1, o, inv, t_max, tr);
-                if (hl) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
-                if (hr) { stk.put(sp, make_uint2(r0.w, asu(tr))); sp = stk.up(sp); }
+                if (hl && hr) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
+                kind = NODE_INSTANCE; // nothing more in this step unless the next child says otherwise
+                if (hl || hr)
+                {
+                    const uint2 next = hr ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
+                    const uint32_t nk = next.x >> NODE_KIND_SHIFT;
+                    if ((nk & 1u) != 0u || (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS_ANY))
+                    {
+                        kind = nk;
+                        payload = next.x & NODE_PAYLOAD_MASK;
+                        t_enter = asf(next.y);
+                    }
+                    else { stk.put(sp, next); sp = stk.up(sp); }
+                }
             }
-            else
+            if (kind & 1u)
             {
                 uint32_t first, count;
                 leaf_range(bl, kind, payload, first, count);

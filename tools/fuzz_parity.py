@@ -40,5 +40,7 @@ for seed in range(first, first + count):
         bad += 1
         print("MISMATCH seed", seed, flush=True)
     r.close()
+    if (seed - first + 1) % 500 == 0:
+        print(f"{seed - first + 1} scenes so far, {bad} mismatches, {time.time() - t0:.1f} s", flush=True)
 print(f"{count} scenes, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--batch-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-ms", action="store_true", help="skip the extra untimed step that times every kernel category (profiling runs: counters then cover the timed steps only)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every launch INSIDE the timed region (diagnostic, slower)")
     args = ap.parse_args()
 
@@ -130,7 +131,7 @@ def main():
         rays, paths = float(st.rays), float(st.paths)
 
     kernel_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_kernel_ms:
         # every kernel category timed, in a SECOND, untimed step (HIP events around every launch serialise the side stream and add
         # idle time, so they stay out of the timed region)
         r.set_config(flags=api.FLAG_TIMING_ALL)

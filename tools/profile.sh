@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O" && mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o r1 -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$O/kt.log" 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o r1 -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-ms > "$O/kt.log" 2>&1
 echo "kernel trace done"
 i=1
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -14,7 +14,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
            "FETCH_SIZE" \
            "WRITE_SIZE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
-    timeout -k 5 300 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o r1 -- python "$R/bench.py" --steps 1 --warmup 0 --spp 43 --no-cpu-baseline > "$O/pmc$i.log" 2>&1
+    timeout -k 5 300 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o r1 -- python "$R/bench.py" --steps 1 --warmup 0 --spp 43 --no-cpu-baseline --no-kernel-ms > "$O/pmc$i.log" 2>&1
     echo "pmc pass $i done"
     i=$((i + 1))
 done

@@ -134,6 +134,12 @@ int pt_create_ray(pt_ctx* ctx, float s, float t, float o[3], float d[3]); /* hos
  *   id         : (id << 16) | new_id applied once per sample (main.rs:206); in/out
  * Blocking. */
 int pt_render(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples, float* data_rgba, float* position_xyzt, uint32_t* id);
+/* The rectangle of pixels camera rays are generated for (host computation, no GPU): columns [rect[0], rect[0]+rect[1]) and LOCAL rows
+ * [rect[2], rect[2]+rect[3]) of this rank.  Every camera ray of a pixel outside it misses the world TLAS's root box (returned in
+ * root_box as min xyz, max xyz when non-NULL), which is all TLAS::intersect would find out (tlas.rs:68-72): such pixels receive the miss
+ * result of integrator.rs:263-266 without a path.  The whole frame when an environment map is set, when the box reaches behind the
+ * image plane, or with PT_FLAG_NO_PRIMARY_CULL. */
+int pt_active_pixels(pt_ctx* ctx, uint32_t rect[4], float root_box[6]);
 /* same, results stay on the device (no host copy); *_dev may be NULL or device pointers of the sizes above */
 int pt_render_device(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples);
 int pt_reset_accumulation(pt_ctx* ctx);

@@ -30,7 +30,7 @@ DEFAULT_SEED = 0x5EED5EED
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
-    "pt_read_accumulation", "pt_render_samples", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
+    "pt_read_accumulation", "pt_render_samples", "pt_active_pixels", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_step_stats",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
@@ -105,6 +105,7 @@ def lib():
         L.pt_create_ray.argtypes = [vp, C.c_float, C.c_float, vp, vp]
         L.pt_render.argtypes = [vp, u32, u32, vp, vp, vp]
         L.pt_render_device.argtypes = [vp, u32, u32]
+        L.pt_active_pixels.argtypes = [vp, vp, vp]
         L.pt_reset_accumulation.argtypes = [vp]
         L.pt_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.pt_read_accumulation.argtypes = [vp, vp]
@@ -301,6 +302,12 @@ class Renderer:
         idb = np.zeros((rows, self.cfg.width), np.uint32) if ident is None else ident
         self._chk(self.L.pt_render(self.ctx, first_sample, n_samples, _p(acc), _p(pos), _p(idb)))
         return acc, pos, idb
+
+    def active_pixels(self):
+        """(x0, width, local row0, rows) of the rectangle camera rays are generated for, and the world root box (min xyz, max xyz)"""
+        rect = np.zeros(4, np.uint32); box = np.zeros(6, np.float32)
+        self._chk(self.L.pt_active_pixels(self.ctx, _p(rect), _p(box)))
+        return tuple(int(v) for v in rect), box
 
     def render_device(self, first_sample: int, n_samples: int):
         self._chk(self.L.pt_render_device(self.ctx, first_sample, n_samples))

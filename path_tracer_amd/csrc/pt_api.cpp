@@ -1033,6 +1033,24 @@ int pt_create_ray(pt_ctx* c, float s, float t, float o[3], float d[3])
     return PT_OK;
 }
 
+int pt_active_pixels(pt_ctx* c, uint32_t rect[4], float root_box[6])
+{
+    if (!c || !rect) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = precheck(c))) return r;
+    const ActiveRect ar = active_rect(c);
+    rect[0] = ar.x0; rect[1] = ar.w; rect[2] = ar.ly0; rect[3] = ar.rows;
+    if (root_box)
+    {
+        const FlatScene& f = c->scene.flat;
+        if (f.world_root == MISS_ID) return fail(c, PT_ERR_STATE, "empty scene");
+        const DNode& n = f.nodes[f.world_root];
+        for (int k = 0; k < 3; ++k) { root_box[k] = n.mn[k]; root_box[3 + k] = n.mx[k]; }
+    }
+    return PT_OK;
+}
+
 int pt_render_device(pt_ctx* c, uint32_t first_sample, uint32_t n_samples)
 {
     if (!c) return PT_ERR_ARG;

@@ -290,3 +290,45 @@ def test_cornell_obj_assets_match_the_generated_scene(api, oracle_mod):
         assert_bit_equal(gp, op, "positions"); assert_bit_equal(gn, on, "normals")
         assert_bit_equal(gp.reshape(-1, 3, 3), m.positions, m.name + " positions survive the text round trip")
         assert np.abs(gn.reshape(-1, 3, 3) - m.normals).max() < 1e-6                          # vn is re-normalised on load (blas.rs:74)
+
+
+@pytest.mark.parametrize("eye,target,fov,aspect,size", [((0.0, 50.0, 1000.0), (0.0, 50.0, 0.0), 60.0, 16 / 9, (192, 108)), ((900.0, 700.0, 1100.0), (0.0, 0.0, 0.0), 35.0, 1.5, (150, 100)),
+                                                        ((0.0, 50.0, 1000.0), (900.0, 50.0, 0.0), 40.0, 1.0, (96, 96)), ((-400.0, 900.0, 600.0), (50.0, 0.0, -50.0), 25.0, 2.0, (200, 100))])
+def test_active_pixel_rectangle_is_conservative(api, eye, target, fov, aspect, size):
+    """Camera rays are generated only inside a rectangle of pixels (pt_active_pixels: the world root box projected onto the image plane,
+    host code, no GPU).  Whatever the jitter, no camera ray of a pixel OUTSIDE it may meet the root box: checked here with the library's own
+    Camera::create_ray and the reference's slab formula (boundingbox.rs:97-113) in binary32 on the rim of the rectangle and on random
+    outside pixels."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Camera, SceneDesc
+    W, H = size
+    sc = SceneDesc.new(scenes.cornell_models(), Camera.new(eye, target, fov, aspect), "view")
+    r = api.Renderer(sc, W, H)
+    (x0, w, y0, rows), box = r.active_pixels()
+    assert 0 < w < W or 0 < rows < H, "this view should leave part of the frame outside the rectangle"
+    mn, mx = box[:3].astype(np.float32), box[3:].astype(np.float32)
+    EPS, INF = np.float32(5e-4), np.float32(np.inf)
+
+    def hits(o, d):                                           # AABB::intersect with t_max = infinity
+        with np.errstate(all="ignore"):
+            inv = (np.float32(1.0) / d).astype(np.float32)
+            t0, t1 = ((mn - o) * inv).astype(np.float32), ((mx - o) * inv).astype(np.float32)
+            sse_max = lambda a, b: np.where(a > b, a, b)      # _mm_max_ps(a, b): b when either is NaN
+            sse_min = lambda a, b: np.where(a < b, a, b)
+            small = sse_min(sse_max(t0, EPS), sse_max(t1, EPS))
+            big = sse_max(sse_min(t0, INF), sse_min(t1, INF))
+            return small.max() <= big.min()
+
+    rng = np.random.default_rng(3)
+    outside = [(x, y) for x in range(W) for y in range(H) if not (x0 <= x < x0 + w and y0 <= y < y0 + rows)]
+    rim = [(x, y) for (x, y) in outside if x0 - 1 <= x <= x0 + w and y0 - 1 <= y <= y0 + rows]
+    pick = rim + [outside[i] for i in rng.choice(len(outside), min(300, len(outside)), replace=False)]
+    assert pick
+    for (x, y) in pick:
+        for ox, oy in ((-0.5, -0.5), (0.5, -0.5), (-0.5, 0.5), (0.5, 0.5), (0.0, 0.0), tuple(rng.uniform(-0.5, 0.5, 2))):
+            o, d = r.create_ray(np.float32((x + ox) / W), np.float32((y + oy) / H))
+            assert not hits(np.asarray(o, np.float32), np.asarray(d, np.float32)), (x, y, ox, oy)
+    # ... and the rectangle is not needlessly large: some ray of its own rim does meet the box
+    k = 6  # three pixels of margin, one of rounding, and the corner of the projected hull need not touch the rectangle's edge midway
+    inner = [(x, y) for x in (x0 + k, x0 + w - 1 - k) for y in range(y0 + k, y0 + rows - k)] + [(x, y) for y in (y0 + k, y0 + rows - 1 - k) for x in range(x0 + k, x0 + w - k)]
+    assert any(hits(*[np.asarray(v, np.float32) for v in r.create_ray(np.float32((x + 0.5) / W), np.float32((y + 0.5) / H))]) for (x, y) in inner)

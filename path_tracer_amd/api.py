@@ -86,6 +86,14 @@ def lib():
             path = _build.LIB_PATH
             if _build.is_stale():
                 path = _build.build()
+        # One HIP runtime per process: torch ships its own libamdhip64 / libhsa-runtime64 / librccl, and a process that has already
+        # opened the GPU through /opt/rocm's copies cannot open it again through torch's ("No HIP GPUs are available").  This module
+        # hands device pointers to torch (framebuffer_tensor, dist.gather_framebuffer), so torch's copies go in first and libptmi binds
+        # to them by soname.  A C/C++/Rust host that never loads torch uses /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         vp, u32, f32p = C.c_void_p, C.c_uint32, C.c_void_p
         L.pt_create.restype = vp

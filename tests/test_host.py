@@ -332,3 +332,21 @@ def test_active_pixel_rectangle_is_conservative(api, eye, target, fov, aspect, s
     k = 6  # three pixels of margin, one of rounding, and the corner of the projected hull need not touch the rectangle's edge midway
     inner = [(x, y) for x in (x0 + k, x0 + w - 1 - k) for y in range(y0 + k, y0 + rows - k)] + [(x, y) for y in (y0 + k, y0 + rows - 1 - k) for x in range(x0 + k, x0 + w - k)]
     assert any(hits(*[np.asarray(v, np.float32) for v in r.create_ray(np.float32((x + 0.5) / W), np.float32((y + 0.5) / H))]) for (x, y) in inner)
+
+
+def test_python_host_loads_one_hip_runtime():
+    # torch ships its own HIP/HSA/RCCL; loading /opt/rocm's first and torch's second leaves torch without a GPU.  api.lib() must
+    # end with exactly one libamdhip64 and one libhsa-runtime64 mapped, whichever module a test file touches first.
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from path_tracer_amd import api\n"
+        "api.lib()\n"
+        "import torch\n"
+        "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l}\n"
+        "print(sorted(libs))\n"
+        "assert len(libs) == 2, libs\n" % ROOT
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

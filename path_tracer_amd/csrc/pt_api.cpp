@@ -25,7 +25,10 @@ using namespace pt;
 #define PT_SHADE_BLOCKS_PER_CU 12  // persistent shading workgroups per CU (same-box sweep over 4, 6, 8, 12, 16)
 #endif
 #ifndef PT_JOIN_LATE
-#define PT_JOIN_LATE 0  // same-box A/B: joining the side stream only before the shading pass costs +2 ms per frame (the two traversal kernels fight for wave slots), 0.1 ms less for a 1/8 share
+#define PT_JOIN_LATE 0 // same-box A/B: joining the side stream only before the shading pass costs +2 ms per frame (the two traversal kernels fight for wave slots), 0.1 ms less for a 1/8 share
+#endif
+#ifndef PT_INTERLEAVE_FIRST
+#define PT_INTERLEAVE_FIRST 1 // the first batches of the pipelines are enqueued bounce by bounce across the pipelines (render_common)
 #endif
 #ifndef PT_SIDE_PRIORITY
 #define PT_SIDE_PRIORITY 0
@@ -488,6 +491,7 @@ int ensure_wavefront(pt_ctx* c, int pipe, size_t n_paths, uint32_t rows)
     TAKE(w.q_shade_base, (size_t)std::max(n_classes, 1u) * 3 * w.q_stride * 16);
     TAKE(w.counters, (size_t)rows * sizeof(Counters));
     TAKE(w.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4);
+    TAKE(w.tails, (size_t)rows * Q_COUNT * kTailWordsPerQueue * 4);
 #undef TAKE
     w.cap_slots = (uint32_t)n_slots;
     w.cap_slots_shade = (uint32_t)n_slots_shade;
@@ -590,11 +594,38 @@ int harvest_batch(pt_ctx* c, int pipe)
 // one wavefront batch: samples [first, first+count) of every local pixel, launched on pipeline `pipe` (nothing here waits for the
 // device except the emptiness probes of very long bounce budgets).  `after`: event the batch's accumulation must wait for (the
 // previous batch's accumulation: samples are added to the frame in sample order), or null.
-int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples, hipEvent_t after)
+// One batch's launches, cut at the bounces so that the batches of several pipelines can be enqueued side by side (render_common):
+// batch_begin, batch_bounce(0..max_bounces), batch_end.  Everything is asynchronous on the pipeline's streams except the
+// every-fourth-bounce look at the counters that long bounce budgets use to stop early.
+struct BatchRun
+{
+    pt_ctx* c = nullptr;
+    int pipe = 0;
+    RenderParams rp{};
+    CameraView cam{};
+    EnvView env{};
+    TraceLaunch tl{}, tl_side{};
+    hipStream_t s = nullptr;
+    uint32_t rows = 0, shade_blocks = 1, last_row = 0, count = 0;
+    bool nee = false, side_busy = false, stopped = false, write_position = false, aux_with_samples = false;
+    int nee_err = PT_OK;
+    f4* samples_out = nullptr;
+    hipEvent_t after = nullptr;
+};
+
+int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples, hipEvent_t after)
 {
     pt_ctx::Pipe& pp = c->pipe[pipe];
     const pt_config& g = c->cfg;
-    RenderParams rp{};
+    br = BatchRun{};
+    br.c = c;
+    br.pipe = pipe;
+    br.count = count;
+    br.write_position = write_position;
+    br.samples_out = samples_out;
+    br.aux_with_samples = aux_with_samples;
+    br.after = after;
+    RenderParams& rp = br.rp;
     rp.width = g.width;
     rp.height = g.height;
     rp.local_rows = (uint32_t)c->rows.size();
@@ -618,105 +649,135 @@ int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, boo
     rp.div_act_w = fastdiv_make(rp.act_w);
     rp.div_width = fastdiv_make(rp.width);
     rp.div_strip_rows = fastdiv_make(rp.strip_rows);
-    const uint32_t rows = g.max_bounces + 2;
-    hipStream_t s = c->pipe_stream(pipe);
+    br.rows = g.max_bounces + 2;
+    br.last_row = br.rows - 1;
+    br.s = c->pipe_stream(pipe);
     const WavefrontBuffers& wb = pp.wb;
-    const TraceLaunch tl = trace_launch(c, pipe, false), tl_side = trace_launch(c, pipe, true);
-    CameraView cam{};
-    std::memcpy(cam.ray_matrix, c->scene.camera.ray_matrix, 64);
-    cam.eye[0] = c->scene.camera.matrix.t.x;
-    cam.eye[1] = c->scene.camera.matrix.t.y;
-    cam.eye[2] = c->scene.camera.matrix.t.z;
-    EnvView env{};
+    br.tl = trace_launch(c, pipe, false);
+    br.tl_side = trace_launch(c, pipe, true);
+    std::memcpy(br.cam.ray_matrix, c->scene.camera.ray_matrix, 64);
+    br.cam.eye[0] = c->scene.camera.matrix.t.x;
+    br.cam.eye[1] = c->scene.camera.matrix.t.y;
+    br.cam.eye[2] = c->scene.camera.matrix.t.z;
     if (c->env_w)
     {
-        env.data = (const f4*)c->d_env.p; // uploaded by the caller (ensure_environment)
-        env.w = c->env_w;
-        env.h = c->env_h;
+        br.env.data = (const f4*)c->d_env.p; // uploaded by the caller (ensure_environment)
+        br.env.w = c->env_w;
+        br.env.h = c->env_h;
     }
+    HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)br.rows * sizeof(Counters), br.s));
+    HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)br.rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, br.s));
+    HIPCHK(c, hipMemsetAsync(wb.tails, 0, (size_t)br.rows * Q_COUNT * kTailWordsPerQueue * 4, br.s));
+    if (rp.n_paths) { Timer t(c, pp, br.s, T_GEN); launch_generate(br.s, rp, br.cam, wb); }
+    br.shade_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU));
+    br.nee = g.enable_nee != 0;
+    return PT_OK;
+}
 
-    HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)rows * sizeof(Counters), s));
-    HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, s));
-    if (rp.n_paths) { Timer t(c, pp, s, T_GEN); launch_generate(s, rp, cam, wb); }
-    const uint32_t shade_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU));
-    const bool nee = g.enable_nee != 0;
-    // The BSDF-sampled NEE launch of a bounce has almost nothing to do since shading answers the rays that miss the lights' root box
-    // (it is all launch latency and tail).  It runs on a side stream beside the shadow-ray launch; the main stream waits for it before
-    // the next closest-hit launch (waiting only before the next SHADING pass, the first reader of its results, was measured: +2 ms per
-    // frame, the two traversal kernels fight for wave slots).
-    int nee_err = PT_OK;
-    bool side_busy = false;
-    auto nee_launches = [&](uint32_t row) {
-        const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
-        if (timing_all)
-        {
-            { Timer t(c, pp, s, T_ANY); launch_trace_shadow(s, tl, wb, row); }
-            { Timer t(c, pp, s, T_LIGHT); launch_trace_lchain(s, tl, wb, row); }
-            return;
-        }
-        if (hipEventRecord(pp.ev_fork, s) != hipSuccess || hipStreamWaitEvent(pp.side_stream, pp.ev_fork, 0) != hipSuccess) nee_err = PT_ERR_HIP;
-        launch_trace_lchain(pp.side_stream, tl_side, wb, row);
-        if (hipEventRecord(pp.ev_join, pp.side_stream) != hipSuccess) nee_err = PT_ERR_HIP;
-        side_busy = true;
-        launch_trace_shadow(s, tl, wb, row);
-    };
-    auto join_side = [&]() {
-        if (!side_busy) return;
-        if (hipStreamWaitEvent(s, pp.ev_join, 0) != hipSuccess) nee_err = PT_ERR_HIP;
-        side_busy = false;
-    };
-    uint32_t last_row = rows - 1;
-    for (uint32_t b = 0; b <= g.max_bounces; ++b)
+// The BSDF-sampled NEE launch of a bounce has almost nothing to do since shading answers the rays that miss the lights' root box
+// (it is all launch latency and tail).  It runs on a side stream beside the shadow-ray launch; the main stream waits for it before
+// the next closest-hit launch (waiting only before the next SHADING pass, the first reader of its results, was measured: +2 ms per
+// frame, the two traversal kernels fight for wave slots).
+void batch_nee_launches(BatchRun& br, uint32_t row)
+{
+    pt_ctx* c = br.c;
+    pt_ctx::Pipe& pp = c->pipe[br.pipe];
+    const WavefrontBuffers& wb = pp.wb;
+    const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
+    if (timing_all)
     {
-        if (b > 0 && nee)
-        {
-            nee_launches(b - 1);
-        }
+        { Timer t(c, pp, br.s, T_ANY); launch_trace_shadow(br.s, br.tl, wb, row); }
+        { Timer t(c, pp, br.s, T_LIGHT); launch_trace_lchain(br.s, br.tl, wb, row); }
+        return;
+    }
+    if (hipEventRecord(pp.ev_fork, br.s) != hipSuccess || hipStreamWaitEvent(pp.side_stream, pp.ev_fork, 0) != hipSuccess) br.nee_err = PT_ERR_HIP;
+    launch_trace_lchain(pp.side_stream, br.tl_side, wb, row);
+    if (hipEventRecord(pp.ev_join, pp.side_stream) != hipSuccess) br.nee_err = PT_ERR_HIP;
+    br.side_busy = true;
+    launch_trace_shadow(br.s, br.tl, wb, row);
+}
+
+void batch_join_side(BatchRun& br)
+{
+    if (!br.side_busy) return;
+    if (hipStreamWaitEvent(br.s, br.c->pipe[br.pipe].ev_join, 0) != hipSuccess) br.nee_err = PT_ERR_HIP;
+    br.side_busy = false;
+}
+
+int batch_bounce(BatchRun& br, uint32_t b)
+{
+    if (br.stopped) return PT_OK;
+    pt_ctx* c = br.c;
+    pt_ctx::Pipe& pp = c->pipe[br.pipe];
+    const pt_config& g = c->cfg;
+    const WavefrontBuffers& wb = pp.wb;
+    hipStream_t s = br.s;
+    if (b > 0 && br.nee) batch_nee_launches(br, b - 1);
 #if !PT_JOIN_LATE
-        join_side();
+    batch_join_side(br);
 #endif
-        { Timer t(c, pp, s, T_WORLD); launch_trace_world(s, tl, wb, b, rp, cam, env); }
-        join_side();
-        for (uint32_t q = 0; q < Q_COUNT; ++q)
-            if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, rp, wb, b, shade_blocks, cam, env); }
-        // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
-        if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
-        {
-            HIPCHK(c, hipMemcpyAsync(pp.h_counters + b + 1, wb.counters + b + 1, sizeof(Counters), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            const Counters& nx = pp.h_counters[b + 1];
-            if (nx.n_closest == 0) { last_row = b + 1; break; }
-        }
+    { Timer t(c, pp, s, T_WORLD); launch_trace_world(s, br.tl, wb, b, br.rp, br.cam, br.env); }
+    batch_join_side(br);
+    for (uint32_t q = 0; q < Q_COUNT; ++q)
+        if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, br.rp, wb, b, br.shade_blocks, br.cam, br.env); }
+    // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
+    if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
+    {
+        HIPCHK(c, hipMemcpyAsync(pp.h_counters + b + 1, wb.counters + b + 1, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const Counters& nx = pp.h_counters[b + 1];
+        if (nx.n_closest == 0) { br.last_row = b + 1; br.stopped = true; }
     }
-    if (last_row == rows - 1) last_row = g.max_bounces + 1;
+    return PT_OK;
+}
+
+int batch_end(BatchRun& br)
+{
+    pt_ctx* c = br.c;
+    pt_ctx::Pipe& pp = c->pipe[br.pipe];
+    const pt_config& g = c->cfg;
+    const WavefrontBuffers& wb = pp.wb;
+    hipStream_t s = br.s;
+    const RenderParams& rp = br.rp;
+    if (br.last_row == br.rows - 1) br.last_row = g.max_bounces + 1;
     // the last shading pass may still owe direct-light estimates: trace them, then a resolve-only terminal pass
-    if (nee)
+    if (br.nee)
     {
-        nee_launches(last_row - 1);
-        join_side();
-        { Timer t(c, pp, s, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, last_row, shade_blocks, cam, env); }
+        batch_nee_launches(br, br.last_row - 1);
+        batch_join_side(br);
+        { Timer t(c, pp, s, T_SHADE); launch_shade(s, Q_TERMINAL, c->sv, rp, wb, br.last_row, br.shade_blocks, br.cam, br.env); }
     }
-    if (nee_err) return fail(c, PT_ERR_HIP, "stream fork/join failed");
-    if (after && hipStreamWaitEvent(s, after, 0) != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamWaitEvent");
-    if (samples_out)
+    if (br.nee_err) return fail(c, PT_ERR_HIP, "stream fork/join failed");
+    if (br.after && hipStreamWaitEvent(s, br.after, 0) != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamWaitEvent");
+    if (br.samples_out)
     {
-        launch_store_samples(s, rp, wb, samples_out);
+        launch_store_samples(s, rp, wb, br.samples_out);
         // pt_frame: the frame's own colour goes to the input texture, position / id history are still updated
-        if (aux_with_samples) launch_accumulate(s, rp, cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, 1u, 0u);
+        if (br.aux_with_samples) launch_accumulate(s, rp, br.cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, 1u, 0u);
     }
     else
     {
         Timer t(c, pp, s, T_ACCUM);
-        launch_accumulate(s, rp, cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, write_position ? 1u : 0u, 1u);
+        launch_accumulate(s, rp, br.cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, br.write_position ? 1u : 0u, 1u);
     }
     HIPCHK(c, hipEventRecord(pp.ev_done, s));
-    HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)br.rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)br.rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
     pp.busy = true;
-    pp.busy_rows = rows;
-    pp.busy_paths = (uint64_t)rp.local_pixels * count;
-    pp.busy_culled = (uint64_t)(rp.local_pixels - rp.act_pixels) * count;
+    pp.busy_rows = br.rows;
+    pp.busy_paths = (uint64_t)rp.local_pixels * br.count;
+    pp.busy_culled = (uint64_t)(rp.local_pixels - rp.act_pixels) * br.count;
     return PT_OK;
+}
+
+int launch_batch(pt_ctx* c, int pipe, uint32_t first_sample, uint32_t count, bool write_position, f4* samples_out, bool aux_with_samples, hipEvent_t after)
+{
+    BatchRun br;
+    int r;
+    if ((r = batch_begin(br, c, pipe, first_sample, count, write_position, samples_out, aux_with_samples, after))) return r;
+    for (uint32_t b = 0; b <= c->cfg.max_bounces; ++b)
+        if ((r = batch_bounce(br, b))) return r;
+    return batch_end(br);
 }
 
 int ensure_environment(pt_ctx* c)
@@ -807,9 +868,32 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         for (uint32_t i = 1; i < n_pipes; ++i) HIPCHK(c, hipStreamWaitEvent(c->pipe_stream((int)i), c->ev_start, 0));
     }
     hipEvent_t prev_done = nullptr;
-    uint32_t k = 0;
     int err = PT_OK;
-    for (uint32_t done = 0; done < n_samples && !err; done += batch, ++k)
+    // The first n_pipes batches find every pipeline idle; their launches are enqueued bounce by bounce ACROSS the pipelines:
+    // enqueueing a whole batch takes the host about a millisecond, which the second pipeline of a short request (one rank's share
+    // of a sharded frame is two batches) would otherwise spend idle, and the first would run its tail alone at the end.  Later
+    // batches go out whole, each as soon as its pipeline's previous batch is done, which keeps the pipelines out of step.
+    uint32_t done = 0, k = 0;
+    if (n_pipes > 1 && PT_INTERLEAVE_FIRST)
+    {
+        BatchRun run[pt_ctx::kMaxPipes];
+        for (uint32_t i = 0; i < n_pipes && done < n_samples && !err; ++i, ++k)
+        {
+            const uint32_t cnt = std::min(batch, n_samples - done);
+            if ((err = harvest_batch(c, (int)i))) break;
+            err = batch_begin(run[i], c, (int)i, first_sample + done, cnt, done + cnt == n_samples, nullptr, false, nullptr);
+            done += cnt;
+        }
+        for (uint32_t b = 0; b <= c->cfg.max_bounces && !err; ++b)
+            for (uint32_t i = 0; i < k && !err; ++i) err = batch_bounce(run[i], b);
+        for (uint32_t i = 0; i < k && !err; ++i)
+        {
+            run[i].after = prev_done; // accumulation stays in sample order
+            if ((err = batch_end(run[i]))) break;
+            prev_done = c->pipe[i].ev_done;
+        }
+    }
+    for (; done < n_samples && !err; done += batch, ++k)
     {
         const int pi = (int)(k % n_pipes);
         const uint32_t cnt = std::min(batch, n_samples - done);

@@ -49,6 +49,20 @@ namespace {
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
 #endif
+// a wave takes part in a launch only if the queue holds this many 64-ray generations for it (fetch_plan)
+#ifndef PT_MIN_GENERATIONS
+#define PT_MIN_GENERATIONS 1
+#endif
+// striped shade-queue tails: see stripes_for
+#ifndef PT_STRIPE_DIV
+#define PT_STRIPE_DIV 64
+#endif
+#ifndef PT_REGIONS_PER_STRIPE
+#define PT_REGIONS_PER_STRIPE 256
+#endif
+#ifndef PT_REGION_DIV
+#define PT_REGION_DIV 16
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -88,7 +102,7 @@ __device__ __forceinline__ FetchPlan fetch_plan(uint32_t n)
     FetchPlan pl;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t need_waves = (n + 63u) >> 6;
-    pl.blocks = min(gridDim.x, (need_waves + wpb - 1u) / wpb);
+    pl.blocks = min(gridDim.x, (need_waves + wpb * (uint32_t)PT_MIN_GENERATIONS - 1u) / (wpb * (uint32_t)PT_MIN_GENERATIONS));
     const uint32_t waves = max(pl.blocks, 1u) * wpb;
     uint32_t c = n / (waves * (uint32_t)PT_CHUNK_DIV);
     c = c < 64u ? 64u : (c > (uint32_t)PT_CHUNK_MAX ? (uint32_t)PT_CHUNK_MAX : c);
@@ -219,7 +233,7 @@ struct Region { uint32_t cur, end; };
 // `least`: the most one reservation has to take in one go (64 for a wave, 256 for a workgroup)
 __device__ __forceinline__ uint32_t region_size(uint32_t n_in, uint32_t producers, uint32_t least)
 {
-    uint32_t r = n_in / (max(producers, 1u) * 16u);
+    uint32_t r = n_in / (max(producers, 1u) * (uint32_t)PT_REGION_DIV);
     r = r < least ? least : (r > kQueueDumpSlots ? (uint32_t)kQueueDumpSlots : r);
     return (r + 63u) & ~63u;
 }
@@ -252,6 +266,70 @@ __device__ __forceinline__ Placement wave_reserve(Region& rg, uint32_t* counter,
     }
     else rg.cur += total;
     return p;
+}
+
+// ---- striped tails (pt_types.h): the same region scheme with the reservations spread over up to 64 tail words
+struct Stripes { uint32_t log_r, log_k; }; // region = 1 << log_r slots, 1 << log_k stripes
+// `n_key` = slots of the bounce's closest-hit input queue: what the producers (k_closest) and the consumers (k_shade_surface) of the
+// bounce's shade queues both know.  Regions of n_key / (4096 * PT_STRIPE_DIV) slots rounded down to a power of two in [64, 8192]
+// (4096 = the traversal waves of a full launch); about PT_REGIONS_PER_STRIPE regions per stripe, so a short queue has one tail
+// and no gaps at all, a long one 64.
+__device__ __forceinline__ Stripes stripes_for(uint32_t n_key)
+{
+    const uint32_t want = n_key / (4096u * (uint32_t)PT_STRIPE_DIV);
+    Stripes st;
+    st.log_r = want < 64u ? 6u : min(13u, 31u - (uint32_t)__clz(want));
+    const uint32_t per = (n_key >> st.log_r) / (uint32_t)PT_REGIONS_PER_STRIPE;
+    st.log_k = per == 0u ? 0u : min(6u, 31u - (uint32_t)__clz(per));
+    return st;
+}
+// one thread: the next region of stripe `rot & (K - 1)`, or the dump area when the queue is full
+__device__ __forceinline__ uint32_t next_region_striped(const Region& rg, uint32_t* tails, const Stripes st, uint32_t rot, uint32_t cap, uint32_t* overflow)
+{
+    if (rg.end > cap) return cap; // already diverted: stay in the dump area
+    const uint32_t k = rot & ((1u << st.log_k) - 1u);
+    const uint32_t r = atomicAdd(tails + k * kTailStrideWords, 1u);
+    const uint64_t base = (((uint64_t)r << st.log_k) | k) << st.log_r;
+    if (base + (1ull << st.log_r) > (uint64_t)cap)
+    {
+        __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return cap;
+    }
+    return (uint32_t)base;
+}
+// wave-uniform, like wave_reserve; `rot` moves on with every reservation so that a producer visits all stripes in turn
+__device__ __forceinline__ Placement wave_reserve_striped(Region& rg, uint32_t* tails, const Stripes st, uint32_t& rot, uint32_t total, uint32_t cap, uint32_t* overflow)
+{
+    Placement p{rg.cur, rg.end - rg.cur, 0u};
+    if (total > p.left)
+    {
+        uint32_t nb = 0;
+        if (lane_id() == 0u) nb = next_region_striped(rg, tails, st, rot, cap, overflow);
+        nb = __builtin_amdgcn_readfirstlane(nb);
+        rot += 1u;
+        p.base1 = nb;
+        rg.cur = nb + (total - p.left);
+        rg.end = nb + (1u << st.log_r);
+    }
+    else rg.cur += total;
+    return p;
+}
+// consumer side.  Lane l of the calling wave loads tail l; returns the queue's extent in slots (clamped to cap), wave-uniform
+__device__ __forceinline__ uint32_t stripe_load(const uint32_t* tails, const Stripes st, uint32_t cap, uint32_t& my_tail)
+{
+    const uint32_t l = lane_id();
+    my_tail = l < (1u << st.log_k) ? tails[l * kTailStrideWords] : 0u;
+    uint64_t e = my_tail != 0u ? (((((uint64_t)(my_tail - 1u)) << st.log_k) | l) + 1ull) << st.log_r : 0ull;
+    e = e > (uint64_t)cap ? (uint64_t)cap : e;
+    uint32_t ext = (uint32_t)e;
+    for (int off = 32; off > 0; off >>= 1) ext = max(ext, (uint32_t)__shfl_xor((int)ext, off));
+    return ext;
+}
+// does slot `idx` lie in a region that some producer reserved?  `tail_of` = the 64 tails (LDS)
+__device__ __forceinline__ bool stripe_valid(const uint32_t* tail_of, const Stripes st, uint32_t idx)
+{
+    const uint32_t g = idx >> st.log_r;
+    return (g >> st.log_k) < tail_of[g & ((1u << st.log_k) - 1u)];
 }
 
 // Block-wide queue append for up to four queues at once: region reservation per workgroup (two barriers, no per-tile atomics).
@@ -478,6 +556,7 @@ struct ClosestOut
     uint32_t q_stride, q_class_slot;
     uint2* q_term;         // terminal queue entries {ray index, path id}
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
+    uint32_t* tails;       // the row's striped tails [Q_COUNT][kTailWordsPerQueue] (surface classes; the terminal queue keeps n_shade[Q_TERMINAL])
     uint32_t cap_shade, cap_term; // queue capacities (slots)
     uint32_t class_mask;   // shade classes present in the scene (bit Q_TERMINAL always set)
     uint32_t* overflow;    // batch-wide "a queue was full" flag
@@ -582,6 +661,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
     const uint32_t rsize = region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
+    const Stripes stripes = stripes_for(plan.n);
+    uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     for (;;)
     {
@@ -679,8 +760,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                             if (!((out.class_mask >> c) & 1u)) continue;
                             const uint64_t m = __ballot(cls == c);
                             if (m == 0ull) continue;
-                            const Placement pl = wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize,
-                                                              c == Q_TERMINAL ? out.cap_term : out.cap_shade, out.overflow);
+                            const Placement pl = c == Q_TERMINAL
+                                ? wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize, out.cap_term, out.overflow)
+                                : wave_reserve_striped(bin_region[c], out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), out.cap_shade, out.overflow);
                             if (cls == c)
                             {
                                 const uint32_t pos = place(pl, mbcnt64(m));
@@ -1219,6 +1301,7 @@ struct ShadeIO
     const f4* hits;           // terminal pass only: hits of the rays that went to the terminal queue, by ray index
     const uint2* entries;     // terminal pass: {ray index | ENTRY_DEAD, path id}
     ShadeQueue q_in;          // surface pass: this class's hit records in queue order
+    const uint32_t* tails_in; // ... and the queue's striped tails
     uint2* q_term_next;
     uint32_t cap_slots, cap_slots_term, cap_slots_shade; // queue capacities (slots)
     Counters* ctr;     // row of this bounce
@@ -1354,8 +1437,23 @@ template <uint32_t QCLASS, bool VOLUMES>
 __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
     __shared__ BlockAppend sh_append;
+    __shared__ uint32_t sh_tail[kTailStripes];
+    __shared__ uint32_t sh_extent;
+    // the queue's extent and the regions the shorter stripes never reached (stripe_valid); keyed like the producer's (k_closest of this bounce)
+    const Stripes stripes = stripes_for(min(io.ctr->n_closest, io.cap_slots));
+    if (threadIdx.x < kTailStripes)
+    {
+        uint32_t mine;
+        const uint32_t ext = stripe_load(io.tails_in, stripes, io.cap_slots_shade, mine);
+        sh_tail[threadIdx.x] = mine;
+        if (threadIdx.x == 0u)
+        {
+            sh_extent = ext;
+            if (blockIdx.x == 0u) io.ctr->n_shade[QCLASS] = ext; // for the host's per-bounce table only
+        }
+    }
     block_append_init(sh_append);
-    const uint32_t n = min(io.ctr->n_shade[QCLASS], io.cap_slots_shade);
+    const uint32_t n = sh_extent;
     const uint32_t rsize = region_size(n, min(gridDim.x, (n + blockDim.x - 1u) / blockDim.x), 256u);
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     uint32_t culled = 0;
@@ -1370,7 +1468,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
     {
         const f4 rb = a_next;
         a_next = (idx + stride) < n ? nt_load(io.q_in.a + idx + stride) : hole_a;
-        bool valid = asu(rb.w) != HOLE;
+        bool valid = idx < n && stripe_valid(sh_tail, stripes, idx) && asu(rb.w) != HOLE;
         bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
         uint32_t pid = 0, flags = 0;
@@ -1875,6 +1973,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     out.q_class_slot = wb.q_class_slot;
     out.q_term = wb.q_term[b & 1u];
     out.n_shade = row->n_shade;
+    out.tails = wb.tails + (size_t)b * Q_COUNT * kTailWordsPerQueue;
     out.cap_shade = wb.cap_slots_shade;
     out.cap_term = wb.cap_slots_term;
     out.class_mask = wb.class_mask | (1u << Q_TERMINAL);
@@ -1933,7 +2032,11 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.lchain_hit = wb.lchain_hit;
     io.hits = wb.hits;
     io.entries = wb.q_term[b & 1u];
-    if (qclass != Q_TERMINAL) io.q_in = shade_queue(wb, qclass);
+    if (qclass != Q_TERMINAL)
+    {
+        io.q_in = shade_queue(wb, qclass);
+        io.tails_in = wb.tails + ((size_t)b * Q_COUNT + qclass) * kTailWordsPerQueue;
+    }
     io.q_term_next = wb.q_term[(b + 1u) & 1u];
     io.cap_slots = wb.cap_slots;
     io.cap_slots_term = wb.cap_slots_term;

@@ -225,6 +225,14 @@ enum : uint32_t { HEAD_CURSOR = 0, HEAD_TALLY0 = 1, HEAD_TALLY1 = 2, HEAD_TALLY2
 // every queue is allocated with this many slots past its capacity: a producer that finds the queue full diverts its writes there
 // (see wave_reserve) instead of past the end
 enum : uint32_t { kQueueDumpSlots = 8192u };
+// Striped queue tails (the surface classes' shade queues).  A returning atomic on ONE tail word sustains ~88 reservations per
+// microsecond; a 1/8 share of the frame wants ~70.  So a queue's regions are handed out by up to kTailStripes tail words, each in a
+// cache line of its own: region r of stripe k is global region r * K + k, i.e. slots [(r * K + k) << log_r, ... + (1 << log_r)).
+// Producers rotate through the stripes, so the stripes stay within a few regions of each other and the queue stays dense up to the
+// regions the shorter stripes never reached; the consumer reads the K tails once and skips those regions (stripe_valid).  Region
+// size and stripe count are powers of two derived from the size of the bounce's input queue (stripes_for), which producer and
+// consumer both know.
+enum : uint32_t { kTailStripes = 64u, kTailStrideWords = 32u, kTailWordsPerQueue = kTailStripes * kTailStrideWords };
 
 // Shade queue of one surface class: what the shading pass needs of a hit, written by the traversal kernel in queue order and read
 // back linearly (no gather by ray index):  a = direction.xyz | path id,  b = t, u, v | hit id,  c = origin.xyz | unused.

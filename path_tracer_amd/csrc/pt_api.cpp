@@ -30,6 +30,9 @@ using namespace pt;
 #ifndef PT_INTERLEAVE_FIRST
 #define PT_INTERLEAVE_FIRST 1 // the first batches of the pipelines are enqueued bounce by bounce across the pipelines (render_common)
 #endif
+#ifndef PT_WAVE_TIMES
+#define PT_WAVE_TIMES 0
+#endif
 #ifndef PT_SIDE_PRIORITY
 #define PT_SIDE_PRIORITY 0
 #endif
@@ -492,6 +495,9 @@ int ensure_wavefront(pt_ctx* c, int pipe, size_t n_paths, uint32_t rows)
     TAKE(w.counters, (size_t)rows * sizeof(Counters));
     TAKE(w.heads, (size_t)rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4);
     TAKE(w.tails, (size_t)rows * Q_COUNT * kTailWordsPerQueue * 4);
+#if PT_WAVE_TIMES
+    TAKE(w.wave_times, (size_t)rows * kWaveTimeSlots * 16);
+#endif
 #undef TAKE
     w.cap_slots = (uint32_t)n_slots;
     w.cap_slots_shade = (uint32_t)n_slots_shade;
@@ -668,6 +674,9 @@ int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32
     HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)br.rows * sizeof(Counters), br.s));
     HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)br.rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, br.s));
     HIPCHK(c, hipMemsetAsync(wb.tails, 0, (size_t)br.rows * Q_COUNT * kTailWordsPerQueue * 4, br.s));
+#if PT_WAVE_TIMES
+    HIPCHK(c, hipMemsetAsync(wb.wave_times, 0, (size_t)br.rows * kWaveTimeSlots * 16, br.s));
+#endif
     if (rp.n_paths) { Timer t(c, pp, br.s, T_GEN); launch_generate(br.s, rp, br.cam, wb); }
     br.shade_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU));
     br.nee = g.enable_nee != 0;
@@ -1929,6 +1938,56 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
     const pt_ctx::Pipe& pp = c->pipe[c->last_pipe];
     if (!pp.h_heads) return PT_ERR_STATE;
     const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
+#if PT_WAVE_TIMES
+    // diagnostic build: the eight words are a reduction of the per-wave time records of the row's k_closest launch instead:
+    // ~min start, max end, sum of lifetimes, sum of (queue empty - start), waves, ~min and max of "queue empty", sum of (first rays - start)
+    {
+        std::vector<uint32_t> rec((size_t)rows * kWaveTimeSlots * 4);
+        if (hipMemcpy(rec.data(), pp.wb.wave_times, rec.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return PT_ERR_HIP;
+        for (uint32_t r = 0; r < rows; ++r)
+        {
+            uint32_t* o = rows8 + 8 * r;
+            std::memset(o, 0, 32);
+            uint32_t t0 = 0; bool any = false;
+            for (uint32_t w = 0; w < kWaveTimeSlots; ++w)
+            {
+                const uint32_t* q = &rec[((size_t)r * kWaveTimeSlots + w) * 4];
+                if (q[3] == 0u) continue;
+                if (!any || (int32_t)(q[0] - t0) < 0) t0 = q[0];
+                any = true;
+            }
+            if (!any) continue;
+            uint32_t max_end = 0, min_dr = 0xffffffffu, max_dr = 0;
+            for (uint32_t w = 0; w < kWaveTimeSlots; ++w)
+            {
+                const uint32_t* q = &rec[((size_t)r * kWaveTimeSlots + w) * 4];
+                if (q[3] == 0u) continue;
+                max_end = std::max(max_end, q[3] - t0);
+                min_dr = std::min(min_dr, q[2] - t0);
+                max_dr = std::max(max_dr, q[2] - t0);
+                o[2] += q[3] - q[0];
+                o[3] += q[2] - q[0];
+                o[4] += 1u;
+                o[7] += q[1] - q[0];
+            }
+            o[0] = ~t0; o[1] = t0 + max_end; o[5] = ~(t0 + min_dr); o[6] = t0 + max_dr;
+            if (std::getenv("PTMI_WAVE_TIMES_DUMP"))
+            {
+                std::vector<uint32_t> ends;
+                for (uint32_t w = 0; w < kWaveTimeSlots; ++w)
+                {
+                    const uint32_t* q = &rec[((size_t)r * kWaveTimeSlots + w) * 4];
+                    if (q[3] != 0u) ends.push_back(q[3] - t0);
+                }
+                std::sort(ends.begin(), ends.end());
+                std::fprintf(stderr, "row %u ends (us) p1 %.0f p10 %.0f p25 %.0f p50 %.0f p75 %.0f p90 %.0f p99 %.0f max %.0f\n", r, ends[ends.size() / 100] * 0.01, ends[ends.size() / 10] * 0.01,
+                             ends[ends.size() / 4] * 0.01, ends[ends.size() / 2] * 0.01, ends[ends.size() * 3 / 4] * 0.01, ends[ends.size() * 9 / 10] * 0.01, ends[ends.size() * 99 / 100] * 0.01, ends.back() * 0.01);
+            }
+        }
+        *n_rows = rows;
+        return PT_OK;
+    }
+#endif
     for (uint32_t r = 0; r < rows; ++r)
     {
         uint32_t* o = rows8 + 8 * r;

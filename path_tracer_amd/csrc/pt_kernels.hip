@@ -49,6 +49,10 @@ namespace {
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
 #endif
+// PT_WAVE_TIMES (variant builds, tools/wave_times.py): when the waves of a k_closest launch start, first have rays, find the queue empty, end
+#ifndef PT_WAVE_TIMES
+#define PT_WAVE_TIMES 0
+#endif
 // a wave takes part in a launch only if the queue holds this many 64-ray generations for it (fetch_plan)
 #ifndef PT_MIN_GENERATIONS
 #define PT_MIN_GENERATIONS 1
@@ -68,6 +72,10 @@ namespace {
 #endif
 #ifndef PT_CHUNK_DIV
 #define PT_CHUNK_DIV 4
+#endif
+// scenes whose BVH stays in global memory have long rays: smaller chunks, shorter launch tails (same-box A/B on the 82 k / 328 k meshes: -3 % / -7 %)
+#ifndef PT_CHUNK_DIV_GLOBAL_BVH
+#define PT_CHUNK_DIV_GLOBAL_BVH 16
 #endif
 constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
 constexpr int kStepsAny = PT_STEPS_ANY;
@@ -97,14 +105,14 @@ struct FetchPlan
     uint32_t guide;    // a dynamic claim takes (what is left of the partition) / guide slots: chunks shrink as the queue drains
     uint32_t blocks;   // workgroups that take part
 };
-__device__ __forceinline__ FetchPlan fetch_plan(uint32_t n)
+__device__ __forceinline__ FetchPlan fetch_plan(uint32_t n, uint32_t chunk_div)
 {
     FetchPlan pl;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t need_waves = (n + 63u) >> 6;
     pl.blocks = min(gridDim.x, (need_waves + wpb * (uint32_t)PT_MIN_GENERATIONS - 1u) / (wpb * (uint32_t)PT_MIN_GENERATIONS));
     const uint32_t waves = max(pl.blocks, 1u) * wpb;
-    uint32_t c = n / (waves * (uint32_t)PT_CHUNK_DIV);
+    uint32_t c = n / (waves * chunk_div);
     c = c < 64u ? 64u : (c > (uint32_t)PT_CHUNK_MAX ? (uint32_t)PT_CHUNK_MAX : c);
     pl.chunk = (c + 63u) & ~63u;
     pl.n = n;
@@ -131,7 +139,17 @@ struct WaveRange
     uint32_t nx_len;  // ... for this many slots
     uint32_t nx_got;  // ... and this is the atomic's return value (lane 0)
 };
-__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t) { return pl.chunk; } // (shrinking claims towards the end of a partition: +1 ms per frame, no gain for a 1/8 share)
+#ifndef PT_GUIDED
+#define PT_GUIDED 0
+#endif
+// what a claim takes, given what the wave last saw of the partition's cursor
+__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t seen)
+{
+    if (!PT_GUIDED) return pl.chunk; // (shrinking claims towards the end of a partition: +1 ms per frame, no gain for a 1/8 share)
+    const uint32_t left = pl.psize - min(seen, pl.psize);
+    const uint32_t want = (left / pl.guide) & ~63u;
+    return want < 64u ? 64u : min(want, pl.chunk);
+}
 __device__ __forceinline__ void prefetch_claim(WaveRange& wr, uint32_t* heads, const FetchPlan& pl)
 {
     wr.nx_valid = true;
@@ -556,6 +574,7 @@ struct ClosestOut
     uint32_t q_stride, q_class_slot;
     uint2* q_term;         // terminal queue entries {ray index, path id}
     uint32_t* n_shade;     // counters row: n_shade[Q_COUNT]
+    uint4* wave_times;     // PT_WAVE_TIMES builds: [kWaveTimeSlots] records of this launch, else unused
     uint32_t* tails;       // the row's striped tails [Q_COUNT][kTailWordsPerQueue] (surface classes; the terminal queue keeps n_shade[Q_TERMINAL])
     uint32_t cap_shade, cap_term; // queue capacities (slots)
     uint32_t class_mask;   // shade classes present in the scene (bit Q_TERMINAL always set)
@@ -633,7 +652,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                                                   uint32_t* __restrict__ heads, const ClosestOut out)
 {
     extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in));
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH);
     if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
@@ -657,6 +676,10 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
 #if PT_STEP_STATS
     uint32_t st_iter = 0, st_lane_active = 0, st_lane_inst = 0, st_lane_branch = 0, st_lane_leaf = 0, st_wave_inst = 0, st_wave_branch = 0, st_wave_leaf = 0;
 #endif
+#if PT_WAVE_TIMES
+    const uint32_t tw_start = (uint32_t)wall_clock64();
+    uint32_t tw_first = 0u, tw_drained = 0u;
+#endif
     Region bin_region[Q_COUNT];
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
@@ -668,6 +691,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
     {
         uint64_t act = __ballot(active);
         const bool no_more = wr.drained && wr.cur >= wr.end;
+#if PT_WAVE_TIMES
+        if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
+#endif
         const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
         if (service)
         {
@@ -846,6 +872,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                 else { pending = true; }
                 } // not a hole
             }
+#if PT_WAVE_TIMES
+            if (tw_first == 0u && take != 0u) tw_first = (uint32_t)wall_clock64() | 1u;
+#endif
             act = __ballot(active);
             if (act == 0ull) continue; // retires the lanes that missed the root box, then refills again or exits
         }
@@ -1037,6 +1066,18 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
             for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
         }
     }
+#if PT_WAVE_TIMES
+    // one record per wave (100 MHz ticks, low 32 bits): start, first rays, queue found empty, end; the host reduces them
+    // (pt_last_batch_step_stats in a PT_WAVE_TIMES build, tools/wave_times.py)
+    if (lane_id() == 0u && out.wave_times)
+    {
+        const uint32_t tw_end = (uint32_t)wall_clock64();
+        if (tw_drained == 0u) tw_drained = tw_end;
+        if (tw_first == 0u) tw_first = tw_start;
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wave < kWaveTimeSlots) out.wave_times[wave] = make_uint4(tw_start, tw_first, tw_drained, tw_end | 1u);
+    }
+#endif
 #if PT_STEP_STATS
     // words 8..15 of the cursor lines: wave-steps executed, lanes active in them, lanes taking the instance / branch / leaf section, and
     // (words 13..15) wave-steps in which at least one lane took that section; tools/step_stats.py reads these.
@@ -1072,7 +1113,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
                                               f4* __restrict__ radiance)
 {
     extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in));
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH);
     if (blockIdx.x >= plan.blocks) return;
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
@@ -1768,6 +1809,7 @@ __device__ __forceinline__ f3 finalise(f3 acc)
 // accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206.  One thread per LOCAL pixel; a pixel
 // outside the active rectangle (RenderParams::act_*) never had a path: each of its samples is the miss result of integrator.rs:263-266
 // — radiance 0.006, id 255, position r.at(1e5) of that sample's camera ray (:156-157) — added sample by sample like any other.
+template <bool FEW_PIXELS>
 __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const CameraView cam, const PathState st, f4* accum, f4* position, uint32_t* id,
                                                      const uint32_t write_position, const uint32_t add_to_accum)
 {
@@ -1791,8 +1833,10 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
         return;
     }
     const uint32_t k = (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0);
-    // eight samples' loads in flight at a time (the sum must be taken in sample order, the loads need not wait for each other)
-    constexpr uint32_t G = 8;
+    // eight samples' loads in flight at a time (the sum must be taken in sample order, the loads need not wait for each other).
+    // FEW_PIXELS (one rank's share of a sharded frame: too few threads to hide latency): sixteen, and the radiance load does not
+    // wait for the miss byte (a primary miss's record is stale memory inside the allocation; it is read and dropped)
+    constexpr uint32_t G = FEW_PIXELS ? 16 : 8;
     for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += G)
     {
         uint32_t oc[G];
@@ -1800,7 +1844,15 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
 #pragma unroll
         for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
 #pragma unroll
-        for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+        for (uint32_t j = 0; j < G; ++j)
+        {
+            if (FEW_PIXELS)
+            {
+                const f4 r = (s0 + j) < rp.batch_samples ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{};
+                rad[j] = oc[j] != PRIMARY_MISS ? r : f4{0.006f, 0.006f, 0.006f, 0.0f};
+            }
+            else rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+        }
 #pragma unroll
         for (uint32_t j = 0; j < G; ++j)
         {
@@ -1974,6 +2026,7 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     out.q_term = wb.q_term[b & 1u];
     out.n_shade = row->n_shade;
     out.tails = wb.tails + (size_t)b * Q_COUNT * kTailWordsPerQueue;
+    out.wave_times = wb.wave_times ? wb.wave_times + (size_t)b * kWaveTimeSlots : nullptr;
     out.cap_shade = wb.cap_slots_shade;
     out.cap_term = wb.cap_slots_term;
     out.class_mask = wb.class_mask | (1u << Q_TERMINAL);
@@ -2071,7 +2124,8 @@ void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& 
                        uint32_t write_position, uint32_t add_to_accum)
 {
     const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
+    if (rp.local_pixels < (1u << 20)) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
 }
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)
 {

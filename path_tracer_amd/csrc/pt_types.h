@@ -232,6 +232,7 @@ enum : uint32_t { kQueueDumpSlots = 8192u };
 // regions the shorter stripes never reached; the consumer reads the K tails once and skips those regions (stripe_valid).  Region
 // size and stripe count are powers of two derived from the size of the bounce's input queue (stripes_for), which producer and
 // consumer both know.
+enum : uint32_t { kWaveTimeSlots = 8192u }; // PT_WAVE_TIMES diagnostic builds: per-wave records of a k_closest launch
 enum : uint32_t { kTailStripes = 64u, kTailStrideWords = 32u, kTailWordsPerQueue = kTailStripes * kTailStrideWords };
 
 // Shade queue of one surface class: what the shading pass needs of a hit, written by the traversal kernel in queue order and read

@@ -497,6 +497,7 @@ int ensure_wavefront(pt_ctx* c, int pipe, size_t n_paths, uint32_t rows)
     TAKE(w.tails, (size_t)rows * Q_COUNT * kTailWordsPerQueue * 4);
 #if PT_WAVE_TIMES
     TAKE(w.wave_times, (size_t)rows * kWaveTimeSlots * 16);
+    TAKE(w.wave_times_any, (size_t)rows * kWaveTimeSlots * 16);
 #endif
 #undef TAKE
     w.cap_slots = (uint32_t)n_slots;
@@ -676,6 +677,7 @@ int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32
     HIPCHK(c, hipMemsetAsync(wb.tails, 0, (size_t)br.rows * Q_COUNT * kTailWordsPerQueue * 4, br.s));
 #if PT_WAVE_TIMES
     HIPCHK(c, hipMemsetAsync(wb.wave_times, 0, (size_t)br.rows * kWaveTimeSlots * 16, br.s));
+    HIPCHK(c, hipMemsetAsync(wb.wave_times_any, 0, (size_t)br.rows * kWaveTimeSlots * 16, br.s));
 #endif
     if (rp.n_paths) { Timer t(c, pp, br.s, T_GEN); launch_generate(br.s, rp, br.cam, wb); }
     br.shade_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + 255) / 256, (size_t)c->n_cus * PT_SHADE_BLOCKS_PER_CU));
@@ -1943,7 +1945,9 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
     // ~min start, max end, sum of lifetimes, sum of (queue empty - start), waves, ~min and max of "queue empty", sum of (first rays - start)
     {
         std::vector<uint32_t> rec((size_t)rows * kWaveTimeSlots * 4);
-        if (hipMemcpy(rec.data(), pp.wb.wave_times, rec.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return PT_ERR_HIP;
+        const char* which = std::getenv("PTMI_WAVE_TIMES_KERNEL"); // "any": the shadow-ray launches instead of the closest-hit ones
+        const uint4* src = (which && which[0] == 'a') ? pp.wb.wave_times_any : pp.wb.wave_times;
+        if (hipMemcpy(rec.data(), src, rec.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return PT_ERR_HIP;
         for (uint32_t r = 0; r < rows; ++r)
         {
             uint32_t* o = rows8 + 8 * r;

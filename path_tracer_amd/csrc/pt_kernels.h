@@ -35,7 +35,8 @@ struct WavefrontBuffers
     uint2* q_term[2];     // terminal queue {ray index | path id + ENTRY_DEAD, path id}, double buffered by bounce parity
     Counters* counters;   // [max_bounces + 2]
     uint32_t* heads;      // [max_bounces + 2][HEADS_PER_ROW][kHeadWordsPerQueue] claim cursors of the ray queues
-    uint4* wave_times;    // PT_WAVE_TIMES builds only: [max_bounces + 2][kWaveTimeSlots], else nullptr
+    uint4* wave_times;    // PT_WAVE_TIMES builds only: [max_bounces + 2][kWaveTimeSlots] (k_closest launches), else nullptr
+    uint4* wave_times_any; // ... the same for the shadow-ray launches
     uint32_t* tails;      // [max_bounces + 2][Q_COUNT][kTailWordsPerQueue] striped tails of the shade queues (pt_types.h)
     uint32_t cap_slots;   // capacity of every ray queue (each allocated with kQueueDumpSlots more)
     uint32_t cap_slots_shade; // capacity of the surface shade queues (= cap_slots except in the overflow test)

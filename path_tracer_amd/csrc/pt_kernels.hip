@@ -67,6 +67,16 @@ namespace {
 #ifndef PT_REGION_DIV
 #define PT_REGION_DIV 16
 #endif
+// tapered chunks: 64-ray chunks per wave in a queue's last level (0 = chunks of one size; chunk_of)
+#ifndef PT_TAPER
+#define PT_TAPER 2
+#endif
+#ifndef PT_TAPER_ANY
+#define PT_TAPER_ANY 0
+#endif
+#ifndef PT_RESERVICE
+#define PT_RESERVICE 1
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -102,10 +112,35 @@ struct FetchPlan
     uint32_t chunk;    // rays per static chunk, and the most a dynamic claim takes; multiple of 64
     uint32_t n_static; // slots [0, n_static) are owned statically, chunk by chunk, by the participating waves
     uint32_t psize;    // slots per dynamic partition, multiple of 64
-    uint32_t guide;    // a dynamic claim takes (what is left of the partition) / guide slots: chunks shrink as the queue drains
+    uint32_t lvl;      // the last `lvl` slots of a partition are handed out 64 at a time, the 2 lvl before them 128 at a time, ... (chunk_of)
     uint32_t blocks;   // workgroups that take part
 };
-__device__ __forceinline__ FetchPlan fetch_plan(uint32_t n, uint32_t chunk_div)
+// The chunks of a partition, in the order they are handed out: big ones first, small ones last, so that what the waves still hold
+// when the queue runs dry — each its current chunk and the one it claimed ahead — is little.  (Per-wave time records of a 17 M-ray
+// launch, tools/wave_times.py: with 1024-ray chunks throughout the waves end anywhere in the last 590 us of 1510, an average wave
+// idles for the last 18 % of the launch; with 128-ray chunks throughout they end within 90 us of each other, but every chunk
+// boundary costs ~5 us of a wave's time — a refill cut short — and the launch is no shorter.)  The cursor of a partition counts
+// chunks, not slots.  false: the partition has no chunk i.
+__device__ __forceinline__ bool chunk_of(const FetchPlan& pl, uint32_t i, uint32_t& start, uint32_t& len)
+{
+    uint32_t rem = pl.psize, base = 0u;
+    const uint32_t e64 = min(rem, pl.lvl); rem -= e64;
+    const uint32_t e128 = min(rem, 2u * pl.lvl); rem -= e128;
+    const uint32_t e256 = min(rem, 4u * pl.lvl); rem -= e256;
+    const uint32_t e512 = min(rem, 8u * pl.lvl); rem -= e512;
+    const uint32_t e1024 = rem;
+#define PT_LEVEL(E, C)                                                                                     \
+    {                                                                                                      \
+        const uint32_t c = min((uint32_t)(C), pl.chunk), cnt = ((E) + c - 1u) / c;                          \
+        if (i < cnt) { start = base + i * c; len = min(c, (E) - i * c); return true; }                      \
+        i -= cnt;                                                                                          \
+        base += (E);                                                                                       \
+    }
+    PT_LEVEL(e1024, 1024u) PT_LEVEL(e512, 512u) PT_LEVEL(e256, 256u) PT_LEVEL(e128, 128u) PT_LEVEL(e64, 64u)
+#undef PT_LEVEL
+    return false;
+}
+__device__ __forceinline__ FetchPlan fetch_plan(uint32_t n, uint32_t chunk_div, uint32_t taper)
 {
     FetchPlan pl;
     const uint32_t wpb = blockDim.x >> 6;
@@ -120,15 +155,14 @@ __device__ __forceinline__ FetchPlan fetch_plan(uint32_t n, uint32_t chunk_div)
     pl.n_static = st >= n ? n : (uint32_t)st;
     const uint32_t units = (n - pl.n_static + 63u) >> 6;
     pl.psize = ((units + kQueueHeads - 1u) / kQueueHeads) << 6;
-    // a partition is shared by waves / kQueueHeads waves on average; each takes half its fair share of what is left
-    pl.guide = max(1u, 2u * waves / kQueueHeads);
+    // over all partitions the 64-ray level holds PT_TAPER chunks per wave (`taper`; 2 = the current one and the one claimed ahead)
+    pl.lvl = taper ? ((taper * waves * 64u / kQueueHeads + 63u) & ~63u) : 0u;
     return pl;
 }
 struct WaveRange
 {
     uint32_t cur, end;
     uint32_t home;    // partition this wave tries first
-    uint32_t seen;    // what this wave last knew of its home partition's cursor (sizes the next claim)
     bool drained;     // the queue has no chunk left for this wave
     // The claim for the chunk AFTER the current one is issued when the current one is taken up and its answer is looked at only
     // when the current one runs out, so the atomic's round trip overlaps the traversal instead of stalling the wave (a same-box
@@ -136,34 +170,23 @@ struct WaveRange
     // the wave always looks at the answer before it leaves.
     bool nx_valid;    // a claim is outstanding
     uint32_t nx_p;    // ... on this partition
-    uint32_t nx_len;  // ... for this many slots
-    uint32_t nx_got;  // ... and this is the atomic's return value (lane 0)
+    uint32_t nx_got;  // ... and this is the atomic's return value (lane 0): the chunk's index in the partition
 };
-#ifndef PT_GUIDED
-#define PT_GUIDED 0
-#endif
-// what a claim takes, given what the wave last saw of the partition's cursor
-__device__ __forceinline__ uint32_t claim_len(const FetchPlan& pl, uint32_t seen)
-{
-    if (!PT_GUIDED) return pl.chunk; // (shrinking claims towards the end of a partition: +1 ms per frame, no gain for a 1/8 share)
-    const uint32_t left = pl.psize - min(seen, pl.psize);
-    const uint32_t want = (left / pl.guide) & ~63u;
-    return want < 64u ? 64u : min(want, pl.chunk);
-}
 __device__ __forceinline__ void prefetch_claim(WaveRange& wr, uint32_t* heads, const FetchPlan& pl)
 {
     wr.nx_valid = true;
     wr.nx_p = wr.home;
-    wr.nx_len = claim_len(pl, wr.seen);
-    if (lane_id() == 0u) wr.nx_got = atomicAdd(heads + wr.home * kHeadStrideWords, wr.nx_len);
+    if (lane_id() == 0u) wr.nx_got = atomicAdd(heads + wr.home * kHeadStrideWords, 1u);
 }
-// [start, start + len) of partition p, clipped to the partition and to the queue; false if nothing of it exists
-__device__ __forceinline__ bool take_claim(WaveRange& wr, const FetchPlan& pl, uint32_t p, uint32_t got, uint32_t len)
+// chunk `idx` of partition p, clipped to the queue; false if nothing of it exists
+__device__ __forceinline__ bool take_claim(WaveRange& wr, const FetchPlan& pl, uint32_t p, uint32_t idx)
 {
     const uint32_t dyn = pl.n - pl.n_static;
-    const uint64_t off = (uint64_t)p * pl.psize + got;
-    if (got >= pl.psize || off >= dyn) return false;
-    const uint64_t stop = min(min(off + len, (uint64_t)(p + 1u) * pl.psize), (uint64_t)dyn);
+    uint32_t start, len;
+    if (!chunk_of(pl, idx, start, len)) return false;
+    const uint64_t off = (uint64_t)p * pl.psize + start;
+    if (off >= dyn) return false;
+    const uint64_t stop = min(off + len, (uint64_t)dyn);
     wr.cur = pl.n_static + (uint32_t)off;
     wr.end = pl.n_static + (uint32_t)stop;
     return true;
@@ -176,11 +199,9 @@ __device__ __forceinline__ WaveRange first_range(const FetchPlan& pl, uint32_t* 
     wr.cur = lo >= pl.n_static ? pl.n : (uint32_t)lo;
     wr.end = lo >= pl.n_static ? pl.n : (uint32_t)min((uint64_t)pl.n_static, lo + pl.chunk);
     wr.home = (wave * 7u) & (kQueueHeads - 1u); // neighbouring waves start on different cursors
-    wr.seen = 0u;
     wr.drained = pl.n_static >= pl.n;            // nothing is handed out dynamically
     wr.nx_valid = false;
     wr.nx_p = 0u;
-    wr.nx_len = 0u;
     wr.nx_got = 0u;
     if (!wr.drained) prefetch_claim(wr, heads, pl);
     return wr;
@@ -195,24 +216,23 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, c
         {
             const uint32_t got = __builtin_amdgcn_readfirstlane(wr.nx_got);
             wr.nx_valid = false;
-            wr.seen = got + wr.nx_len;
-            have = take_claim(wr, pl, wr.nx_p, got, wr.nx_len);
+            have = take_claim(wr, pl, wr.nx_p, got);
         }
         const uint32_t l = lane_id();
         while (!have) // the home partition is empty: look at all cursors; at most kQueueHeads rounds (a failed claim = an empty partition)
         {
             const uint32_t h = __hip_atomic_load(heads + l * kHeadStrideWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t m = __ballot(h < pl.psize && (uint64_t)l * pl.psize + h < (uint64_t)(pl.n - pl.n_static));
+            uint32_t st_l = 0u, len_l = 0u;
+            const bool more = chunk_of(pl, h, st_l, len_l) && (uint64_t)l * pl.psize + st_l < (uint64_t)(pl.n - pl.n_static);
+            const uint64_t m = __ballot(more);
             if (m == 0ull) { wr.drained = true; wr.cur = wr.end = pl.n; break; }
             const uint64_t rot = wr.home == 0u ? m : ((m >> wr.home) | (m << (64u - wr.home)));
             const uint32_t p = (wr.home + (uint32_t)__builtin_ctzll(rot)) & (kQueueHeads - 1u);
-            const uint32_t len = claim_len(pl, (uint32_t)__builtin_amdgcn_readlane((int)h, (int)p)); // readlane, not a shuffle: the claim state stays in SGPRs
             uint32_t got = 0;
-            if (l == 0u) got = atomicAdd(heads + p * kHeadStrideWords, len);
+            if (l == 0u) got = atomicAdd(heads + p * kHeadStrideWords, 1u);
             got = __builtin_amdgcn_readfirstlane(got);
             wr.home = p;
-            wr.seen = got + len;
-            have = take_claim(wr, pl, p, got, len);
+            have = take_claim(wr, pl, p, got);
         }
         if (!wr.drained) prefetch_claim(wr, heads, pl);
     }
@@ -645,6 +665,9 @@ struct Stack8<true>
     }
 };
 
+#if PT_WAVE_TIMES
+__device__ uint4* g_any_times = nullptr; // where the shadow-ray launch in flight puts its per-wave time records (set in-stream by launch_trace_shadow)
+#endif
 // ------------------------------------------------------------------------------------------------ closest hit
 template <bool LDS_SCENE, int MODE, bool SPILL>
 __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
@@ -652,7 +675,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
                                                   uint32_t* __restrict__ heads, const ClosestOut out)
 {
     extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH);
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
     if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
@@ -877,6 +900,8 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
 #endif
             act = __ballot(active);
             if (act == 0ull) continue; // retires the lanes that missed the root box, then refills again or exits
+            // the wave's chunk ended inside this refill: go round again at once for the next chunk instead of stepping with idle lanes
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)kRefillBelow) continue;
         }
 
 #pragma unroll 1
@@ -1113,7 +1138,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
                                               f4* __restrict__ radiance)
 {
     extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH);
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY);
     if (blockIdx.x >= plan.blocks) return;
     uint32_t blob_words;
     const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
@@ -1148,12 +1173,19 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
         else occluded[out_idx] = v;
     };
     bool in_blas = false;
+#if PT_WAVE_TIMES
+    const uint32_t tw_start = (uint32_t)wall_clock64();
+    uint32_t tw_drained = 0u;
+#endif
     WaveRange wr = first_range(plan, heads);
 
     for (;;)
     {
         uint64_t act = __ballot(active);
         const bool no_more = wr.drained && wr.cur >= wr.end;
+#if PT_WAVE_TIMES
+        if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
+#endif
         const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
         if (service)
         {
@@ -1193,6 +1225,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
             }
             act = __ballot(active);
             if (act == 0ull) continue;
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)kRefillBelow) continue;
         }
 
 #pragma unroll 1
@@ -1267,6 +1300,15 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
         }
     }
     if (MODE == ANY_SHADOW) add_tally(heads, valid_rays, HEAD_TALLY0);
+#if PT_WAVE_TIMES
+    if (MODE == ANY_SHADOW && lane_id() == 0u && g_any_times)
+    {
+        const uint32_t tw_end = (uint32_t)wall_clock64();
+        if (tw_drained == 0u) tw_drained = tw_end;
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wave < kWaveTimeSlots) g_any_times[wave] = make_uint4(tw_start, tw_start, tw_drained, tw_end | 1u);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ path bookkeeping
@@ -2055,6 +2097,12 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
     Counters* row = wb.counters + b;
+#if PT_WAVE_TIMES
+    {
+        uint4* where = wb.wave_times_any ? wb.wave_times_any + (size_t)b * kWaveTimeSlots : nullptr;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_any_times), &where, sizeof(where), 0, hipMemcpyHostToDevice, s);
+    }
+#endif
     launch_any_impl<ANY_SHADOW>(s, tl, tl.scene.world_root, wb.rq_shadow, &row->n_shadow, wb.cap_slots, row_heads(wb, b, HEADS_SHADOW),
                                 reinterpret_cast<uint32_t*>(wb.st.rec), wb.st.radiance);
 }

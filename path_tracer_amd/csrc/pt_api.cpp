@@ -847,14 +847,9 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     uint32_t batch = c->cfg.batch_spp ? c->cfg.batch_spp : (uint32_t)std::max<size_t>(1, max_paths / act_pixels);
     batch = std::min(batch, n_samples);
     uint32_t n_batches = (n_samples + batch - 1) / batch;
-    // A request that fits at once but is small (one rank's share of a sharded frame) is still cut in two: its launches are short
-    // enough that their tails matter, and two half batches on two pipelines hide them (measured on a 1/8 share of the 1080p x 256 spp
-    // frame: -8 %; on the whole frame: +1 %, hence the threshold).
-    if (!c->cfg.batch_spp && n_batches == 1 && want_pipes > 1 && n_samples >= 2 && (uint64_t)n_samples * act_pixels <= ((uint64_t)40 << 20))
-    {
-        batch = (n_samples + 1) / 2;
-        n_batches = 2;
-    }
+    // (A request that fits at once runs as ONE batch on one pipeline.  Cutting a small one — a rank's share of a sharded frame — in two
+    // for two pipelines used to hide its launch tails (-8 %); since the tails were shortened at the source (striped tails, tapered
+    // chunks) it costs 5 % instead: twice the launches, and two persistent kernels fighting for the same wave slots.)
     uint32_t n_pipes = std::min(want_pipes, n_batches);
     if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * act_pixels * n_pipes > max_paths)
     {

@@ -77,6 +77,9 @@ namespace {
 #ifndef PT_RESERVICE
 #define PT_RESERVICE 1
 #endif
+#ifndef PT_CLAIM_AHEAD
+#define PT_CLAIM_AHEAD 0 // rays left in a chunk when the next one is claimed; 0 = as soon as the chunk is taken up (same-box A/B of 64 / 128 / 256: +0.3 ms for a 1/8 share, +3 ms per frame)
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -203,7 +206,7 @@ __device__ __forceinline__ WaveRange first_range(const FetchPlan& pl, uint32_t* 
     wr.nx_valid = false;
     wr.nx_p = 0u;
     wr.nx_got = 0u;
-    if (!wr.drained) prefetch_claim(wr, heads, pl);
+    if (!wr.drained && (PT_CLAIM_AHEAD == 0 || wr.end - wr.cur <= (uint32_t)PT_CLAIM_AHEAD)) prefetch_claim(wr, heads, pl);
     return wr;
 }
 // returns how many of the wave's idle lanes receive a ray; lane i (rank r among idle lanes) gets ray first + r
@@ -234,11 +237,15 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, c
             wr.home = p;
             have = take_claim(wr, pl, p, got);
         }
-        if (!wr.drained) prefetch_claim(wr, heads, pl);
+        if (!wr.drained && PT_CLAIM_AHEAD == 0) prefetch_claim(wr, heads, pl);
     }
     const uint32_t take = min(n_idle, wr.end - wr.cur);
     first = wr.cur;
     wr.cur += take;
+    // The next chunk is claimed when the current one has PT_CLAIM_AHEAD rays left — a couple of refills, time enough for the atomic's
+    // round trip — not when it is taken up: what a wave owns when the queue runs dry is then about one chunk, not two, and the
+    // launch's tail is that much shorter.
+    if (PT_CLAIM_AHEAD != 0 && !wr.nx_valid && !wr.drained && wr.end - wr.cur <= (uint32_t)PT_CLAIM_AHEAD) prefetch_claim(wr, heads, pl);
     return take;
 }
 

@@ -28,6 +28,12 @@ namespace {
 #ifndef PT_REFILL_BELOW
 #define PT_REFILL_BELOW 40
 #endif
+#ifndef PT_STEPS_PER_ROUND_GLOBAL_BVH
+#define PT_STEPS_PER_ROUND_GLOBAL_BVH 4
+#endif
+#ifndef PT_REFILL_BELOW_GLOBAL_BVH
+#define PT_REFILL_BELOW_GLOBAL_BVH 56
+#endif
 #ifndef PT_STEPS_ANY
 #define PT_STEPS_ANY PT_STEPS_PER_ROUND
 #endif
@@ -90,9 +96,15 @@ namespace {
 #ifndef PT_CHUNK_DIV_GLOBAL_BVH
 #define PT_CHUNK_DIV_GLOBAL_BVH 16
 #endif
-constexpr int kStepsPerRound = PT_STEPS_PER_ROUND; // traversal steps between refill checks
-constexpr int kStepsAny = PT_STEPS_ANY;
-constexpr int kRefillBelow = PT_REFILL_BELOW;      // refill idle lanes when at most this many lanes are still traversing
+// traversal steps between refill checks, and: refill idle lanes when at most this many lanes are still traversing.  Scenes whose BVH
+// stays in global memory (long rays, every step waits on L2) want their lanes refilled sooner and more often: same-box A/B of
+// 32…62 lanes x 4…16 steps on the 82 k / 328 k meshes: 56 lanes x 4 steps -6 % / -5 % against the LDS scenes' 40 x 8.
+template <bool LDS_SCENE> struct Refill
+{
+    static constexpr int kSteps = LDS_SCENE ? PT_STEPS_PER_ROUND : PT_STEPS_PER_ROUND_GLOBAL_BVH;
+    static constexpr int kStepsAny = LDS_SCENE ? PT_STEPS_ANY : PT_STEPS_PER_ROUND_GLOBAL_BVH;
+    static constexpr int kBelow = LDS_SCENE ? PT_REFILL_BELOW : PT_REFILL_BELOW_GLOBAL_BVH;
+};
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
@@ -724,7 +736,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
 #if PT_WAVE_TIMES
         if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
 #endif
-        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
         if (service)
         {
             // ---- retire finished lanes
@@ -908,11 +920,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_cl
             act = __ballot(active);
             if (act == 0ull) continue; // retires the lanes that missed the root box, then refills again or exits
             // the wave's chunk ended inside this refill: go round again at once for the next chunk instead of stepping with idle lanes
-            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)kRefillBelow) continue;
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelow) continue;
         }
 
 #pragma unroll 1
-        for (int it = 0; it < kStepsPerRound; ++it)
+        for (int it = 0; it < Refill<LDS_SCENE>::kSteps; ++it)
         {
 #if PT_STEP_STATS
             {
@@ -1193,7 +1205,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
 #if PT_WAVE_TIMES
         if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
 #endif
-        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= kRefillBelow);
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
         if (service)
         {
             if (no_more) break;
@@ -1232,11 +1244,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
             }
             act = __ballot(active);
             if (act == 0ull) continue;
-            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)kRefillBelow) continue;
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelow) continue;
         }
 
 #pragma unroll 1
-        for (int it = 0; it < kStepsAny; ++it)
+        for (int it = 0; it < Refill<LDS_SCENE>::kStepsAny; ++it)
         {
             if (!active) continue;
             if (in_blas && sp == blas_base) in_blas = false;

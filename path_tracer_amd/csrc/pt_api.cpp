@@ -33,6 +33,9 @@ using namespace pt;
 #ifndef PT_WAVE_TIMES
 #define PT_WAVE_TIMES 0
 #endif
+#ifndef PT_SIDE_MIN_PATHS
+#define PT_SIDE_MIN_PATHS (4u << 20)
+#endif
 #ifndef PT_SIDE_PRIORITY
 #define PT_SIDE_PRIORITY 0
 #endif
@@ -695,7 +698,9 @@ void batch_nee_launches(BatchRun& br, uint32_t row)
     pt_ctx::Pipe& pp = c->pipe[br.pipe];
     const WavefrontBuffers& wb = pp.wb;
     const bool timing_all = (c->cfg.flags & PT_FLAG_TIMING_ALL) != 0; // per-launch events want one stream
-    if (timing_all)
+    // a small batch (an interactive 1-spp frame) gains nothing from the second stream and pays ~20 us per bounce for the two
+    // cross-stream event waits: its two launches go out one after the other
+    if (timing_all || br.rp.n_paths < (uint32_t)PT_SIDE_MIN_PATHS)
     {
         { Timer t(c, pp, br.s, T_ANY); launch_trace_shadow(br.s, br.tl, wb, row); }
         { Timer t(c, pp, br.s, T_LIGHT); launch_trace_lchain(br.s, br.tl, wb, row); }

@@ -432,18 +432,18 @@ int ensure_wavefront(pt_ctx* c, int pipe, size_t n_paths, uint32_t rows)
     pp.slack_cfg = c->cfg.queue_slack;
     pp.pixels_cfg = c->local_pixels;
     n_paths = std::max<size_t>(n_paths, 64);
-    // Queues hold slots, not entries: every producer may leave the tail of its last region as holes.  A traversal wave reserves
-    // max(64, n_in / (8 * waves)) slots at a time and a shading workgroup max(256, n_in / (8 * workgroups)) (region_size in
-    // pt_kernels.hip), so the holes of one queue stay below n/8 + 8192 * 64 (one traversal kernel) or n/8 + 4 * 3072 * 256 (the up to
-    // four surface-class shading kernels that append to the same ray queues); the terminal queue is fed by both groups.  The slack is
-    // a sizing rule, not a safety margin: a producer that finds a queue full diverts to the queue's dump area and the batch fails
-    // with PT_ERR_LIMIT (pt_config.queue_slack shrinks the slack so that tests can see exactly that).
+    // The ray queues are dense — a shading workgroup reserves exactly what it appends (block_append4) and a path has at most one ray
+    // per queue and bounce — so they hold n_paths slots.  The shade queues and the terminal queue hold slots, not entries: a
+    // traversal wave reserves regions (64…8192 slots: wave_reserve, wave_reserve_striped) and leaves the tail of its last one as
+    // holes, and the shorter stripes leave gaps; both stay below n/8 + 8192 * 64 per queue.  The slack is a sizing rule, not a safety
+    // margin: a producer that finds a queue full diverts to the queue's dump area and the batch fails with PT_ERR_LIMIT
+    // (pt_config.queue_slack shrinks the slack so that tests can see exactly that).
     const size_t frac = c->cfg.queue_slack ? (c->cfg.queue_slack & 0xffffu) : 128;
     const size_t fixed = c->cfg.queue_slack ? 0 : ((size_t)4 << 20);
-    const size_t n_slots = n_paths + n_paths * frac / 1024 + fixed;
-    const size_t n_slots_term = n_paths + 2 * (n_paths * frac / 1024 + fixed); // two producer groups append here
+    const size_t n_slots = n_paths;
+    const size_t n_slots_term = n_paths + n_paths * frac / 1024 + fixed;
     // test mode: the surface shade queues are SMALLER than the batch (the ray queues cannot be: the camera rays of a batch fill one)
-    const size_t n_slots_shade = (c->cfg.queue_slack & 0x80000000u) ? std::max<size_t>(n_paths * frac / 1024, 64) : n_slots;
+    const size_t n_slots_shade = (c->cfg.queue_slack & 0x80000000u) ? std::max<size_t>(n_paths * frac / 1024, 64) : n_paths + n_paths * frac / 1024 + fixed;
     if (n_slots_term + kQueueDumpSlots >= (1ull << 32)) return fail(c, PT_ERR_LIMIT, "batch too large for 32-bit queue slots");
     pp.cap_slots = n_slots;
     pp.cap_slots_term = n_slots_term;

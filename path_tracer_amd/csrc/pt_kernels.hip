@@ -389,21 +389,20 @@ __device__ __forceinline__ bool stripe_valid(const uint32_t* tail_of, const Stri
     return (g >> st.log_k) < tail_of[g & ((1u << st.log_k) - 1u)];
 }
 
-// Block-wide queue append for up to four queues at once: region reservation per workgroup (two barriers, no per-tile atomics).
+// Block-wide queue append for up to four queues at once: the workgroup reserves EXACTLY what it appends, one atomic per queue and
+// call (two barriers).  Regions per workgroup, as the traversal waves use them, were tried first (region = slots_in / (workgroups * 16),
+// at least 256): fewer atomics, but whatever 3072 workgroups leave of their last regions are holes in the next launch's queue — for
+// a 0.14 M-ray bounce of a 1/8 share 0.4 M of them — and holes cost more than the atomics even where those run at the one-word limit
+// (~88 per microsecond is what a full-speed shading launch makes: 22 entries per ns / 256).  Same-box A/B, exact against regions:
+// whole frame 69.6 -> 69.0 ms, 1/2 share 36.9 -> 35.4, 1/4 19.3 -> 18.6, 1/8 10.8 -> 10.2 ms, 1-spp frame 1.40 -> 1.22 ms, mixed
+// materials 14.5 -> 12.8 ms, 82 k mesh 14.1 -> 13.4 ms.
 struct BlockAppend
 {
     uint32_t wave_cnt[4][4];
     uint32_t wave_rank[4][4]; // rank of the wave's first entry inside the workgroup's tile
-    Placement place[4];
-    Region region[4];         // lives across the workgroup's grid-stride iterations
+    uint32_t base[4];
 };
-__device__ __forceinline__ void block_append_init(BlockAppend& sh)
-{
-    if (threadIdx.x < 4u) sh.region[threadIdx.x] = Region{0u, 0u};
-    __syncthreads();
-}
-__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], uint32_t rsize, const uint32_t caps[4],
-                                              uint32_t* overflow, uint32_t pos[4])
+__device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], const uint32_t caps[4], uint32_t* overflow, uint32_t pos[4])
 {
     const uint32_t wid = threadIdx.x >> 6;
     uint64_t m[4];
@@ -420,22 +419,18 @@ __device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const c
         const uint32_t nw = blockDim.x >> 6;
         uint32_t total = 0;
         for (uint32_t w = 0; w < nw; ++w) { sh.wave_rank[q][w] = total; total += sh.wave_cnt[q][w]; }
-        Region rg = sh.region[q];
-        Placement p{rg.cur, rg.end - rg.cur, 0u};
-        if (total > p.left)
+        uint32_t base = caps[q]; // a full queue: the entries go to its dump area (kQueueDumpSlots >= a workgroup's 256), nothing is stored out of bounds
+        if (total != 0u)
         {
-            const uint32_t nb = next_region(rg, counters[q], rsize, caps[q], overflow);
-            p.base1 = nb;
-            rg.cur = nb + (total - p.left);
-            rg.end = nb + rsize;
+            const uint32_t nb = atomicAdd(counters[q], total);
+            if (nb > caps[q] || total > caps[q] - nb) __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else base = nb;
         }
-        else rg.cur += total;
-        sh.region[q] = rg;
-        sh.place[q] = p;
+        sh.base[q] = base;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pos[q] = place(sh.place[q], sh.wave_rank[q][wid] + mbcnt64(m[q]));
+    for (int q = 0; q < 4; ++q) pos[q] = sh.base[q] + sh.wave_rank[q][wid] + mbcnt64(m[q]);
     __syncthreads(); // the shared tables are rewritten by the next iteration
 }
 
@@ -1554,9 +1549,8 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
             if (blockIdx.x == 0u) io.ctr->n_shade[QCLASS] = ext; // for the host's per-bounce table only
         }
     }
-    block_append_init(sh_append);
+    __syncthreads();
     const uint32_t n = sh_extent;
-    const uint32_t rsize = region_size(n, min(gridDim.x, (n + blockDim.x - 1u) / blockDim.x), 256u);
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     uint32_t culled = 0;
     // Everything this pass needs of a hit arrives in queue order (ShadeQueue): direction | path id, t u v | hit id, origin.  The first
@@ -1816,7 +1810,7 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
         const uint32_t caps[4] = {io.cap_slots, io.cap_slots, io.cap_slots, io.cap_slots_term};
         uint32_t pos[4];
-        block_append4(sh_append, ctrs, preds, rsize, caps, &io.ctr->overflow, pos);
+        block_append4(sh_append, ctrs, preds, caps, &io.ctr->overflow, pos);
         if (want_shadow) { nt_store(io.rq_shadow.a + pos[0], sh_a); nt_store(io.rq_shadow.b + pos[0], sh_b); }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
         if (want_next) { nt_store(io.rq_out.a + pos[2], nx_a); nt_store(io.rq_out.b + pos[2], nx_b); }
@@ -1852,12 +1846,6 @@ __global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const
         }
     }
     add_tally(io.lchain_heads, culled, HEAD_TALLY2);
-    // hand back what is left of this workgroup's regions as holes (ray queues: path id = HOLE)
-    const f4 hole_b{0.0f, 0.0f, 0.0f, asf(HOLE)};
-    for (uint32_t i = sh_append.region[0].cur + threadIdx.x; i < sh_append.region[0].end; i += blockDim.x) io.rq_shadow.b[i] = hole_b;
-    for (uint32_t i = sh_append.region[1].cur + threadIdx.x; i < sh_append.region[1].end; i += blockDim.x) io.rq_lchain.b[i] = hole_b;
-    for (uint32_t i = sh_append.region[2].cur + threadIdx.x; i < sh_append.region[2].end; i += blockDim.x) io.rq_out.b[i] = hole_b;
-    for (uint32_t i = sh_append.region[3].cur + threadIdx.x; i < sh_append.region[3].end; i += blockDim.x) io.q_term_next[i] = make_uint2(HOLE, 0u);
 }
 
 // integrator.rs:272-280: finite check, clamp_length_max(100), alpha 1

@@ -14,7 +14,7 @@ def frames(path):
 f1 = frames(sys.argv[1])[-1]; f8 = frames(sys.argv[2])[-1]; N = float(sys.argv[3])
 tot1 = tot8 = 0
 for (n1, d1, s1), (n8, d8, s8) in zip(f1, f8):
-    assert n1 == n8, (n1, n8)
+    assert n1.split('<')[0] == n8.split('<')[0], (n1, n8)
     if 'k_closest<true, 1' in n1:
         print(f"{n1:32s} {d1:9.1f} {d8:8.1f}  (side stream)"); continue
     tot1 += d1; tot8 += d8

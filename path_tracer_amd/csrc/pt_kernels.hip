@@ -35,7 +35,10 @@ namespace {
 #define PT_REFILL_BELOW_GLOBAL_BVH 56
 #endif
 #ifndef PT_STEPS_ANY
-#define PT_STEPS_ANY PT_STEPS_PER_ROUND
+#define PT_STEPS_ANY 4 // any-hit rays are short: same-box sweep 3 / 4 / 5 / 6 / 8 / 10 / 12: 70.8 / 67.6 / 69.0 / 69.4 / 69.9 / 69.3 / 69.6 ms per frame
+#endif
+#ifndef PT_REFILL_BELOW_ANY
+#define PT_REFILL_BELOW_ANY PT_REFILL_BELOW
 #endif
 // waves per SIMD the compiler must leave room for in the traversal kernels that read the BVH from global memory (they wait on L2)
 #ifndef PT_WAVES_GLOBAL_BVH
@@ -104,6 +107,7 @@ template <bool LDS_SCENE> struct Refill
     static constexpr int kSteps = LDS_SCENE ? PT_STEPS_PER_ROUND : PT_STEPS_PER_ROUND_GLOBAL_BVH;
     static constexpr int kStepsAny = LDS_SCENE ? PT_STEPS_ANY : PT_STEPS_PER_ROUND_GLOBAL_BVH;
     static constexpr int kBelow = LDS_SCENE ? PT_REFILL_BELOW : PT_REFILL_BELOW_GLOBAL_BVH;
+    static constexpr int kBelowAny = LDS_SCENE ? PT_REFILL_BELOW_ANY : PT_REFILL_BELOW_GLOBAL_BVH;
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -1200,7 +1204,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
 #if PT_WAVE_TIMES
         if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
 #endif
-        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelowAny);
         if (service)
         {
             if (no_more) break;
@@ -1239,7 +1243,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) 
             }
             act = __ballot(active);
             if (act == 0ull) continue;
-            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelow) continue;
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelowAny) continue;
         }
 
 #pragma unroll 1

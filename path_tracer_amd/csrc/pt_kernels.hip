@@ -89,6 +89,10 @@ namespace {
 #ifndef PT_CLAIM_AHEAD
 #define PT_CLAIM_AHEAD 0 // rays left in a chunk when the next one is claimed; 0 = as soon as the chunk is taken up (same-box A/B of 64 / 128 / 256: +0.3 ms for a 1/8 share, +3 ms per frame)
 #endif
+// threads per shading workgroup (a workgroup makes one reservation per queue and iteration: block_append4)
+#ifndef PT_SHADE_THREADS
+#define PT_SHADE_THREADS 256
+#endif
 #ifndef PT_CHUNK_MAX
 #define PT_CHUNK_MAX 1024
 #endif
@@ -402,8 +406,8 @@ __device__ __forceinline__ bool stripe_valid(const uint32_t* tail_of, const Stri
 // materials 14.5 -> 12.8 ms, 82 k mesh 14.1 -> 13.4 ms.
 struct BlockAppend
 {
-    uint32_t wave_cnt[4][4];
-    uint32_t wave_rank[4][4]; // rank of the wave's first entry inside the workgroup's tile
+    uint32_t wave_cnt[4][PT_SHADE_THREADS / 64];
+    uint32_t wave_rank[4][PT_SHADE_THREADS / 64]; // rank of the wave's first entry inside the workgroup's tile
     uint32_t base[4];
 };
 __device__ __forceinline__ void block_append4(BlockAppend& sh, uint32_t* const counters[4], const bool pred[4], const uint32_t caps[4], uint32_t* overflow, uint32_t pos[4])
@@ -1535,7 +1539,7 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
 
 // Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
 template <uint32_t QCLASS, bool VOLUMES>
-__global__ void __launch_bounds__(256) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
     __shared__ BlockAppend sh_append;
     __shared__ uint32_t sh_tail[kTailStripes];
@@ -2156,24 +2160,25 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.ctr = wb.counters + b;
     io.lchain_heads = row_heads(wb, b, HEADS_LCHAIN);
     io.ctr_next = wb.counters + b + 1u;
+    const uint32_t surface_blocks = (grid_blocks * 256u + PT_SHADE_THREADS - 1u) / PT_SHADE_THREADS; // grid_blocks is in units of 256 threads
     switch (qclass)
     {
     case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
     case Q_LAMBERT:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_SPECULAR:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_DIELECTRIC:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_GGX:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     default: break;
     }

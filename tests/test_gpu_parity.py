@@ -362,6 +362,26 @@ def test_full_queue_is_reported_not_overrun(api, oracle_mod):
     assert_bit_equal(tight.render_samples(0, 4), want, "same context with the default slack")
 
 
+def test_ray_queues_are_dense_and_shade_queues_nearly(api):
+    """A shading workgroup reserves exactly what it appends: a bounce's ray-queue extents (slots) equal the rays traced from
+    them (the claim-cursor tallies), nothing is a hole.  The shade queues are written in regions by the traversal waves over up to 64
+    striped tails: their extents may exceed the hits by the waves' last regions and the stripes' gaps, a few per cent on a queue this
+    size (holes were measured to cost more than reservations: DESIGN.md section 4)."""
+    from path_tracer_amd import scenes
+    r = api.Renderer(scenes.cornell_box(960, 540), 960, 540, max_bounces=6)
+    r.render_device(0, 8)
+    r.synchronize()
+    rows = r.last_batch_counters().astype(np.int64)
+    assert rows[0][0] == rows[0][13] > 500_000          # camera rays: extent == traced
+    for b in range(1, 7):
+        n_closest, n_shadow, n_lchain = rows[b][0], rows[b - 1][2], rows[b - 1][4]
+        assert n_closest == rows[b][13], (b, n_closest, rows[b][13])              # continuation rays of bounce b
+        assert n_shadow == rows[b - 1][14], (b, n_shadow, rows[b - 1][14])        # shadow rays cast by bounce b-1's shading
+        assert n_lchain == rows[b - 1][6], (b, n_lchain, rows[b - 1][6])          # BSDF-sampled NEE rays that passed the lights' root box
+        lambert_slots = rows[b][9]
+        assert n_closest * 0.5 < lambert_slots <= n_closest * 1.06 + 4096 * 64, (b, lambert_slots, n_closest)
+
+
 def test_scene_edit_adds_a_material_class(api, oracle_mod):
     """render, add a model of a material class the context has not seen (its shade queue does not exist yet), rebuild, render again"""
     from path_tracer_amd import scenes

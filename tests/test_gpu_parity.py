@@ -610,6 +610,11 @@ def test_gather_pad_and_deinterleave_run_on_device_tensors(api, cornell64):
     full = ptdist.assemble_strips(parts, H, W, world, strip)
     assert full.is_cuda
     assert_bit_equal(full.cpu().numpy(), ref, "strips of three ranks padded and de-interleaved on the device")
+    # what gather_framebuffer does with them on rank 0: ONE receive buffer whose chunks are the gather list, one index_select
+    plan = ptdist._plan(H, W, world, strip, parts[0].dtype, dev, True)
+    for dst_chunk, p in zip(plan.parts, parts):
+        dst_chunk.copy_(p)  # stands in for the collective
+    assert_bit_equal(plan.recv.index_select(0, plan.perm).cpu().numpy(), ref, "one receive buffer + row permutation")
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])

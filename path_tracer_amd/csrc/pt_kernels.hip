@@ -278,16 +278,18 @@ __device__ __forceinline__ void add_tally(uint32_t* heads, uint32_t per_lane, ui
     if (total != 0u && lane_id() == 0u) atomicAdd(heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords + word, total);
 }
 
-// Queue appends.  A returning atomic on ONE queue-tail word sustains only some tens of millions of operations per second on
-// MI355X (price list "dequeue"), and a wavefront renderer wants ~10^10 appended entries per second, so nobody appends entry by
-// entry or even wave by wave: a producer (a traversal wave, a shading workgroup) RESERVES a private region of the output
-// queue with one atomic, fills it locally and reserves the next one when it runs out.  Whatever is left of its last region
-// when the producer exits is filled with HOLE markers that consumers skip (they come in runs, so skipping them costs a load per
-// 64); the queue's counter therefore counts slots, not entries.  Region size = slots_in / (producers * 16), clamped to [64, 8192],
-// with only the producers that actually take part counted: holes stay below ~1/32 of a large queue and a small launch stays small
-// (same-box sweep of the divisor: 2 and 4 cost 2-5 ms per frame — holes are not free, a hole is an idle lane until the next refill —,
-// 8, 16 and 32 are within noise of each other; regions shared by the four waves of a workgroup through an LDS cursor cut the tail
-// atomics fourfold but their per-retirement LDS atomic cost 2 ms per frame).
+// Queue appends.  A returning atomic on ONE queue-tail word sustains ~88 operations per microsecond on MI355X (price list
+// "dequeue"), and a wavefront renderer wants ~10^10 appended entries per second, so nobody appends entry by entry:
+//  * a TRAVERSAL WAVE (k_closest -> shade queues) RESERVES a private region of the output queue with one atomic, fills it locally
+//    and reserves the next one when it runs out.  Whatever is left of its last region when the wave exits is filled with HOLE
+//    markers that consumers skip; these queues' extents therefore count slots, not entries.  The surface classes' queues hand their
+//    regions out over up to 64 striped tail words (wave_reserve_striped below); the terminal queue, which sees little traffic, keeps
+//    one tail and regions of slots_in / (waves * 16), clamped to [64, 8192] (region_size);
+//  * a SHADING WORKGROUP (-> ray queues, terminal queue) reserves exactly what it appends, once per queue and iteration
+//    (block_append4): those queues are dense.  Holes are not free — a hole is an idle lane until the next refill — and were measured
+//    to cost more than the reservations they save, see block_append4.
+// (Tried: regions shared by the four waves of a traversal workgroup through an LDS cursor: tail atomics / 4, but the per-retirement
+// LDS atomic cost 2 ms per frame.)
 //
 // Capacity: a reservation that would pass the queue's capacity is diverted to the queue's dump area (kQueueDumpSlots slots past the
 // capacity, shared by everybody who overflows) and raises the batch's overflow flag: nothing is ever stored out of bounds, the

@@ -100,7 +100,8 @@ struct Counters
     uint32_t n_lchain;       // BSDF-sampled NEE rays (lights TLAS closest hit, then world any hit)
     uint32_t spare1;
     uint32_t spare2, spare3;
-    uint32_t n_shade[Q_COUNT];
+    uint32_t n_shade[Q_COUNT];  // [Q_TERMINAL]: the terminal queue's tail (slots).  Surface classes: their queues' tails are striped (kTailStripes
+                                // words each, WavefrontBuffers::tails); the shading pass writes the extent it derived from them here for the host's tables
     uint32_t spare4, spare5, spare6; // (exact ray tallies live in the claim-cursor lines: HEAD_TALLY*)
 };
 static_assert(sizeof(Counters) == 64, "");

@@ -502,22 +502,44 @@ int HostScene::flatten(std::string* err)
         d.mn[0] = b.mn.x; d.mn[1] = b.mn.y; d.mn[2] = b.mn.z;
         d.mx[0] = b.mx.x; d.mx[1] = b.mx.y; d.mx[2] = b.mx.z;
     };
-    // device order of one tree: breadth-first, the children of a branch in adjacent slots (left, right)
+    // Device order of one tree: the children of a branch in adjacent slots (left, right: one 64-byte fetch serves both box tests);
+    // the top kBreadthFirstLevels levels breadth-first (they are hot in every cache anyway), every subtree below them depth-first
+    // (a pair, then the left child's subtree, then the right's), so that a descending ray's next pair is often in the line it
+    // just touched.  Against breadth-first throughout: 82 k / 328 k meshes and the three spheres about -1 % (same-box A/B of 1 / 6 /
+    // 10 / 14 top levels: alike).
+    constexpr int kBreadthFirstLevels = 6;
     auto layout = [](const std::vector<HostNode>& nodes, uint32_t root, uint32_t base, std::vector<uint32_t>& where) -> bool {
         where.assign(nodes.size(), MISS_ID);
         if (root == MISS_ID) return nodes.empty();
-        std::vector<uint32_t> order{root};
         where[root] = base;
         uint32_t next = base + 1u;
-        for (size_t k = 0; k < order.size(); ++k)
+        std::vector<std::pair<uint32_t, int>> frontier{{root, 0}}, deep;
+        for (size_t k = 0; k < frontier.size(); ++k)
         {
-            const HostNode& n = nodes[order[k]];
+            const HostNode& n = nodes[frontier[k].first];
             if (n.kind != NODE_BRANCH) continue;
+            if (frontier[k].second >= kBreadthFirstLevels) { deep.push_back(frontier[k]); continue; }
             where[n.a] = next;
             where[n.b] = next + 1u;
             next += 2u;
-            order.push_back(n.a);
-            order.push_back(n.b);
+            frontier.push_back({n.a, frontier[k].second + 1});
+            frontier.push_back({n.b, frontier[k].second + 1});
+        }
+        for (const auto& d : deep)
+        {
+            std::vector<uint32_t> stack{d.first};
+            while (!stack.empty())
+            {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                const HostNode& n = nodes[i];
+                if (n.kind != NODE_BRANCH) continue;
+                where[n.a] = next;
+                where[n.b] = next + 1u;
+                next += 2u;
+                stack.push_back(n.b);
+                stack.push_back(n.a);
+            }
         }
         return next == base + nodes.size();
     };

@@ -40,12 +40,21 @@ namespace {
 #ifndef PT_REFILL_BELOW_ANY
 #define PT_REFILL_BELOW_ANY PT_REFILL_BELOW
 #endif
-// waves per SIMD the compiler must leave room for in the traversal kernels that read the BVH from global memory (they wait on L2)
+// waves per SIMD the compiler must leave room for in the traversal kernels (second parameter of __launch_bounds__).  BVH in LDS: 4 for
+// both (3 / 5 / 2: within noise).  BVH in global memory (the kernels wait on L2): the any-hit kernel fits 96 VGPRs and runs 5 waves; the
+// closest-hit kernel is asked for 3 — it still allocates ~120 VGPRs, but is scheduled more loosely — same-box A/B on the 82 k / 328 k
+// meshes against 4 / 4: -3.8 % / -5 % (3 / 3: -2 / -4.5 %, 5 / 5: -1.5 / -2 %, 2 / 2: -2 / -3.5 %).
+#ifndef PT_WAVES_LDS_BVH
+#define PT_WAVES_LDS_BVH 4
+#endif
+#ifndef PT_WAVES_LDS_BVH_ANY
+#define PT_WAVES_LDS_BVH_ANY 4
+#endif
 #ifndef PT_WAVES_GLOBAL_BVH
-#define PT_WAVES_GLOBAL_BVH 4
+#define PT_WAVES_GLOBAL_BVH 3
 #endif
 #ifndef PT_WAVES_GLOBAL_BVH_ANY
-#define PT_WAVES_GLOBAL_BVH_ANY 4
+#define PT_WAVES_GLOBAL_BVH_ANY 5
 #endif
 // branch levels expanded per traversal step of k_closest (1 = one node per step)
 #ifndef PT_BRANCH_LEVELS
@@ -694,7 +703,7 @@ __device__ uint4* g_any_times = nullptr; // where the shadow-ray launch in fligh
 #endif
 // ------------------------------------------------------------------------------------------------ closest hit
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                                   const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                                   uint32_t* __restrict__ heads, const ClosestOut out)
 {
@@ -1156,7 +1165,7 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 // tested when its parent is expanded (the instance's BLAS root right after the ray transform) and only nodes that were hit go
 // on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? 4 : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH_ANY : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                               uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                               f4* __restrict__ radiance)

@@ -1,5 +1,6 @@
 """Extended randomized parity run (not part of the test suite): random scenes, per-sample radiance + frame + ray tallies, GPU vs oracle.
-Usage: python tools/fuzz_parity.py [first_seed] [n_seeds]"""
+Usage: python tools/fuzz_parity.py [first_seed] [n_seeds] [width height]   (default: tiny frames, 40x24 / 64x20; a few hundred pixels a side
+exercise the striped tails, tapered chunks and dynamic claims that tiny queues never reach)"""
 import sys
 import time
 
@@ -11,6 +12,8 @@ from path_tracer_amd import api, scenes
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+size = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None
+every = 500 if size is None else 20
 O.build()
 
 
@@ -24,7 +27,7 @@ def bits(a):
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
-    w, h = (40, 24) if seed % 3 else (64, 20)
+    w, h = size if size else ((40, 24) if seed % 3 else (64, 20))
     sc = scenes.random_scene(seed, w, h, with_media=(seed % 2 == 0))
     o = O.Oracle(sc)
     r = api.Renderer(sc, w, h, max_bounces=6 + seed % 9)
@@ -40,7 +43,7 @@ for seed in range(first, first + count):
         bad += 1
         print("MISMATCH seed", seed, flush=True)
     r.close()
-    if (seed - first + 1) % 500 == 0:
+    if (seed - first + 1) % every == 0:
         print(f"{seed - first + 1} scenes so far, {bad} mismatches, {time.time() - t0:.1f} s", flush=True)
 print(f"{count} scenes, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

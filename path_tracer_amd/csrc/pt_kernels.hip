@@ -293,7 +293,7 @@ __device__ __forceinline__ void add_tally(uint32_t* heads, uint32_t per_lane, ui
 //    and reserves the next one when it runs out.  Whatever is left of its last region when the wave exits is filled with HOLE
 //    markers that consumers skip; these queues' extents therefore count slots, not entries.  The surface classes' queues hand their
 //    regions out over up to 64 striped tail words (wave_reserve_striped below); the terminal queue, which sees little traffic, keeps
-//    one tail and regions of slots_in / (waves * 16), clamped to [64, 8192] (region_size);
+//    one tail and regions of 64 slots, or slots_in / (waves * 16) clamped to [64, 8192] when an environment map sends every miss there (region_size);
 //  * a SHADING WORKGROUP (-> ray queues, terminal queue) reserves exactly what it appends, once per queue and iteration
 //    (block_append4): those queues are dense.  Holes are not free — a hole is an idle lane until the next refill — and were measured
 //    to cost more than the reservations they save, see block_append4.
@@ -739,7 +739,10 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     Region bin_region[Q_COUNT];
 #pragma unroll
     for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
-    const uint32_t rsize = region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
+    // the terminal queue's regions.  Without an environment map its entries are rare (paths that also cast a BSDF-sampled NEE ray): the
+    // smallest region a wave can use keeps the queue's extent, and what k_shade_terminal reads, small (whole frame: its first launch
+    // 185 -> ~30 us).  With one, every miss goes there: regions sized like any busy queue's.
+    const uint32_t rsize = out.finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
     const Stripes stripes = stripes_for(plan.n);
     uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 

@@ -260,6 +260,7 @@ int upload_scene(pt_ctx* c)
     sv.blob_bytes = (uint32_t)blob.size();
     sv.stack_entries = f.stack_entries;
     sv.has_volumes = f.has_volumes ? 1u : 0u;
+    sv.trav_flags = f.trav_flags;
 
     // launch geometry of the traversal kernels: BVH in LDS when it is small, per-lane stacks always in LDS
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
@@ -269,7 +270,7 @@ int upload_scene(pt_ctx* c)
 #define PT_STACK_LDS_LEVELS 14
 #endif
     sv.stack_lds = std::min<uint32_t>(sv.stack_entries, c->cfg.stack_lds_levels ? c->cfg.stack_lds_levels : PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8; };
+    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8 + (size_t)PT_CAND_SLOTS * t * 16; }; // + k_closest2's per-lane FIFO
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -1992,13 +1993,16 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
         return PT_OK;
     }
 #endif
+    // PTMI_STEP_STATS_BASE=16: the second group of eight words (PT_STEP_STATS=2 builds: section times)
+    const char* base_env = std::getenv("PTMI_STEP_STATS_BASE");
+    const uint32_t base = base_env && std::atoi(base_env) == 16 ? 16u : 8u;
     for (uint32_t r = 0; r < rows; ++r)
     {
         uint32_t* o = rows8 + 8 * r;
         std::memset(o, 0, 32);
         const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue + HEADS_CLOSEST * kHeadWordsPerQueue;
         for (uint32_t g = 0; g < kQueueHeads; ++g)
-            for (uint32_t k = 0; k < 8; ++k) o[k] += hrow[g * kHeadStrideWords + 8 + k];
+            for (uint32_t k = 0; k < 8; ++k) o[k] += hrow[g * kHeadStrideWords + base + k];
     }
     *n_rows = rows;
     return PT_OK;

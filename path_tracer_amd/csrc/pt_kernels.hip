@@ -63,6 +63,10 @@ namespace {
 #ifndef PT_BRANCH_LEVELS_ANY
 #define PT_BRANCH_LEVELS_ANY 4
 #endif
+// closest-hit traversal with deferred leaves (k_closest2) for the world / primary / hook launches; 0 = the round-2 kernel everywhere
+#ifndef PT_TWO_PHASE
+#define PT_TWO_PHASE 0
+#endif
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
@@ -1159,6 +1163,445 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     if (MODE == CLOSEST_LIGHTS) add_tally(heads, light_hits, HEAD_TALLY1);
 }
 
+// ------------------------------------------------------------------------------------------------ closest hit, leaves deferred
+// The reference's traversal (tlas.rs:66-110, blas.rs:214-256) interleaves two kinds of work — expand a branch, test a leaf's triangles —
+// and a wave that runs it lane by lane pays for both kinds in every step, each with a handful of lanes (profiles/r02_step_stats_cornell.md:
+// 23 of 64 lanes per VALU instruction).  What ties the two together is t_max: a hit found in a leaf prunes the boxes visited after it.
+// But the reference uses t_max in exactly two ways, and both can be postponed:
+//   * AABB::intersect_t(r, t_max) (boundingbox.rs:115-131) is  t_small <= min(t_far, t_max)  =  (t_small <= t_far) && (t_small <= t_max):
+//     a part that does not depend on t_max and a comparison of the entry distance with it.  An entry is pushed with its t_small and popped
+//     later under the test t_enter > t_max (tlas.rs:80-83, blas.rs:222-225) against a t_max that can only have shrunk in between, so the pop
+//     test subsumes the push-time comparison: a node is processed iff its box is met at all and t_enter <= t_max WHEN IT IS POPPED;
+//   * the order of the two children (blas.rs:139-153) compares their entry distances only.
+//   Box entry distances never decrease from a node to its children (a child's box lies inside its parent's, the subtraction and the
+//   multiplication by inv are monotone, NaN planes drop out on both sides; the host checks the nesting, FlatScene::nested_boxes), so a
+//   leaf that passes its own pop test has ancestors (inside its BLAS; and, for a TLAS leaf, inside the TLAS) that passed theirs.
+// So:  PHASE 1 (branch steps) walks the tree in the reference's order — nearer child first — pruning with whatever t_max the lane knows
+// (never smaller than the reference's at that moment: conservative), and instead of testing a leaf it APPENDS it to a per-lane FIFO:
+// {leaf link, entry distance of its box, instance, entry distance of the instance's TLAS box}.  PHASE 2 (leaf rounds) takes the FIFO's entries
+// in order, repeats the two pop tests the reference would have made with the t_max it would have had — the TLAS leaf's when the first
+// leaf of an instance comes up (nothing can change t_max between the instance's pop and its first leaf), then the leaf's own — and tests
+// the triangles (primitive.rs:117-178) exactly as before.  Every wave-step is ONE kind of work; which kind is put to the vote: a leaf round
+// when enough lanes hold a candidate (or nobody can expand a branch), else a branch step.
+// Instances that are not the identity (IDENT = false) keep one object-space ray per lane, so a lane enters the next instance only
+// when its FIFO is empty (it "parks" until the next leaf round).  Scenes whose instances are all the identity (every Cornell configuration)
+// compute the object-space image of the ray once, at refill.
+#ifndef PT_LEAF_VOTE
+#define PT_LEAF_VOTE 24   // lanes holding a candidate that make the next wave-step a leaf round
+#endif
+#ifndef PT_BRANCH_LEVELS2
+#define PT_BRANCH_LEVELS2 2
+#endif
+struct CandRing
+{
+    char* base;
+    uint32_t mine, step; // byte offset of this lane's slot 0; bytes per slot row (16 * blockDim.x)
+    __device__ __forceinline__ static CandRing make(uint4* smem, uint32_t blob_words, const SceneView& sv)
+    {
+        return CandRing{reinterpret_cast<char*>(smem), blob_words * 16u + sv.stack_lds * blockDim.x * 8u + threadIdx.x * 16u, blockDim.x * 16u};
+    }
+    __device__ __forceinline__ uint4 get(uint32_t i) const { return *reinterpret_cast<const uint4*>(base + mine + (i & (uint32_t)(PT_CAND_SLOTS - 1)) * step); }
+    __device__ __forceinline__ void put(uint32_t i, uint4 v) const { *reinterpret_cast<uint4*>(base + mine + (i & (uint32_t)(PT_CAND_SLOTS - 1)) * step) = v; }
+};
+
+template <bool LDS_SCENE, int MODE, bool SPILL, bool IDENT>
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest2(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                                  uint32_t* __restrict__ heads, const ClosestOut out)
+{
+    static_assert(MODE != CLOSEST_LIGHTS, "the fused NEE chain stays on k_closest");
+    extern __shared__ uint4 smem[];
+    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
+    if (blockIdx.x >= plan.blocks) return;
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
+    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv);
+    const CandRing ring = CandRing::make(smem, blob_words, sv);
+    const uint32_t prim_bits = sv.prim_bits;
+
+    bool active = false, pending = false, ray_finite = false, in_blas = false, parked = false, r_pruned = false;
+    uint32_t ray_idx = 0, pid = 0;
+    LaneRay w{}, ob{};
+    float t_max = 0.0f, bt = 0.0f, ts_inst = 0.0f;
+    float hud = 0.0f, hvd = 0.0f, hdet = 1.0f;
+    uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0, r_inst = MISS_ID;
+    uint32_t head = 0, tail = 0; // FIFO read / write positions (mod PT_CAND_SLOTS)
+    WaveRange wr = first_range(plan, heads);
+    uint32_t valid_rays = 0;
+#if PT_STEP_STATS
+    uint32_t st_iter = 0, st_lane_active = 0, st_lane_branch = 0, st_lane_leaf = 0, st_lane_test = 0, st_wave_branch = 0, st_wave_leaf = 0, st_lane_park = 0;
+#endif
+#if PT_STEP_STATS == 2
+    // wave time by section (s_memtime ticks / 64): service, branch steps, leaf rounds; and the number of services
+    uint64_t tt_service = 0, tt_branch = 0, tt_leaf = 0, tt_mark = 0;
+    uint32_t n_service = 0;
+    const uint64_t tt_start = __builtin_readcyclecounter();
+#define PT_TT_BEGIN() tt_mark = __builtin_readcyclecounter()
+#define PT_TT_END(acc) acc += __builtin_readcyclecounter() - tt_mark
+#else
+#define PT_TT_BEGIN()
+#define PT_TT_END(acc)
+#endif
+    Region bin_region[Q_COUNT];
+#pragma unroll
+    for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
+    const uint32_t rsize = out.finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
+    const Stripes stripes = stripes_for(plan.n);
+    uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (;;)
+    {
+        uint64_t act = __ballot(active);
+        const bool no_more = wr.drained && wr.cur >= wr.end;
+        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
+        if (service)
+        {
+            PT_TT_BEGIN();
+#if PT_STEP_STATS == 2
+            n_service += 1u;
+#endif
+            // ---- retire finished lanes (as k_closest)
+            const uint64_t pm = __ballot(pending);
+            if (pm != 0ull)
+            {
+                if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
+                {
+                    uint64_t qm = pm;
+                    if (MODE == CLOSEST_PRIMARY)
+                    {
+                        const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
+                        if (pending) out.occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
+                        if (pending && bid == MISS_ID)
+                        {
+                            // defaults of integrator.rs:156-157 (with an environment map the terminal pass shades the miss)
+                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
+                            if (ray_idx >= out.keep_pos_from)
+                            {
+                                const f3 far = fma3(w.d, bc3(1e5f), w.o);
+                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
+                            }
+                        }
+                        qm = __ballot(pending && !missed);
+                        pending = pending && !missed;
+                    }
+                    if (MODE == CLOSEST_WORLD)
+                    {
+                        // paths that end at this hit or miss are finished here (integrator.rs:207-214, 263-266): see k_closest
+                        bool ends = false, emissive = false;
+                        uint32_t mat_id = 0;
+                        if (pending)
+                        {
+                            if (bid == MISS_ID) ends = out.finalize_miss != 0u;
+                            else
+                            {
+                                const uint4 meta = bl.inst[7u * (bid >> prim_bits) + 6u];
+                                emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
+                                mat_id = meta.z;
+                            }
+                        }
+                        if (ends)
+                        {
+                            const DPathRec& rec = out.rec[pid];
+                            const f4 acc4 = rec.acc;
+                            const uint32_t flags = asu(acc4.w);
+                            if (!(flags & FLAG_BSDF_CAST))
+                            {
+                                f3 acc = xyz(acc4);
+                                if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
+                                const f3 pw = xyz(rec.pw);
+                                if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
+                                else if (!out.enable_nee || (flags & FLAG_LAST_DELTA))
+                                {
+                                    const DMaterial& m = sv.materials[mat_id];
+                                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
+                                }
+                                out.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f};
+                                pending = false;
+                            }
+                        }
+                        qm = __ballot(pending);
+                    }
+                    if (qm != 0ull)
+                    {
+                        uint32_t cls = Q_COUNT;
+                        if (pending) cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
+                        const f4 hit{bt, hud / hdet, hvd / hdet, asf(bid)};
+#pragma unroll
+                        for (uint32_t c = 0; c < Q_COUNT; ++c)
+                        {
+                            if (!((out.class_mask >> c) & 1u)) continue;
+                            const uint64_t m = __ballot(cls == c);
+                            if (m == 0ull) continue;
+                            const Placement pl = c == Q_TERMINAL
+                                ? wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize, out.cap_term, out.overflow)
+                                : wave_reserve_striped(bin_region[c], out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), out.cap_shade, out.overflow);
+                            if (cls == c)
+                            {
+                                const uint32_t pos = place(pl, mbcnt64(m));
+                                if (c == Q_TERMINAL)
+                                {
+                                    out.hits[ray_idx] = hit;
+                                    out.q_term[pos] = make_uint2(ray_idx, pid);
+                                }
+                                else
+                                {
+                                    f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride + pos;
+                                    nt_store(qa, f4{w.d.x, w.d.y, w.d.z, asf(pid)});
+                                    nt_store(qa + out.q_stride, hit);
+                                    if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)out.q_stride, f4{w.o.x, w.o.y, w.o.z, 0.0f});
+                                }
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    if (pending) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
+                }
+                pending = false;
+            }
+            if (no_more) break;
+            // ---- refill idle lanes from the wave's private range
+            const uint64_t idle = ~act;
+            uint32_t first;
+            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(idle), first);
+            const uint32_t rank = mbcnt64(idle);
+            if (!active && rank < take)
+            {
+                const uint32_t mine = first + rank;
+                const f4 b = rb[mine];
+                ray_idx = mine;
+                pid = asu(b.w);
+                if (pid != HOLE) {
+                valid_rays += 1u;
+                if (MODE == CLOSEST_PRIMARY)
+                {
+                    w.o = out.eye;
+                    t_max = asf(0x7f800000u);
+                }
+                else
+                {
+                    const f4 a = ra[mine];
+                    w.o = xyz(a);
+                    t_max = a.w;
+                }
+                w.d = xyz(b);
+                w.inv = rcp3(w.d);
+                ray_finite = finite3(w.o) && finite3(w.d);
+                bid = MISS_ID;
+                bt = asf(0x7f800000u);
+                hud = 0.0f;
+                hvd = 0.0f;
+                hdet = 1.0f;
+                in_blas = false;
+                parked = false;
+                r_inst = MISS_ID;
+                head = tail = 0u;
+                sp = stk.empty();
+                float te;
+                const uint4 root0 = bl.nodes[2u * root];
+                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                if (ok)
+                {
+                    stk.put(sp, make_uint2(root0.w, 0u));    // tlas.rs:74: the root goes in with t_enter 0
+                    sp = stk.up(sp);
+                    active = true;
+                    // every instance is the identity: one object-space image of the ray serves them all (instance 0's matrix is everybody's)
+                    if (IDENT) { uint32_t unused; ob = to_object(bl, 0u, w, ray_finite, unused); }
+                }
+                else { pending = true; }
+                } // not a hole
+            }
+            act = __ballot(active);
+            PT_TT_END(tt_service);
+            if (act == 0ull) continue;
+            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelow) continue;
+        }
+
+#pragma unroll 1
+        for (int it = 0; it < Refill<LDS_SCENE>::kSteps; ++it)
+        {
+            PT_TT_BEGIN();
+            if (active)
+            {
+                if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
+                if (sp == stk.empty() && head == tail) { active = false; pending = true; }
+            }
+            const bool has_c = active && head != tail;
+            const bool can_b = active && sp != stk.empty() && !parked && (tail - head) <= (uint32_t)(PT_CAND_SLOTS - 2);
+            const uint64_t ml = __ballot(has_c), mb = __ballot(can_b);
+#if PT_STEP_STATS
+            if ((ml | mb) != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(__ballot(active)); st_lane_park += (uint32_t)__popcll(__ballot(active && !has_c && !can_b)); }
+#endif
+            if (ml != 0ull && ((uint32_t)__popcll(ml) >= (uint32_t)PT_LEAF_VOTE || mb == 0ull))
+            {
+                // ---- leaf round: the next candidate of every lane that holds one, in the order the reference would have popped them
+#if PT_STEP_STATS
+                if (lane_id() == (uint32_t)__builtin_ctzll(ml)) st_wave_leaf += 1u;
+                st_lane_leaf += has_c ? 1u : 0u;
+#endif
+                if (has_c)
+                {
+                    const uint4 c = ring.get(head);
+                    head += 1u;
+                    if (head == tail) parked = false;
+                    const float t_est = asf(c.y);
+                    // the TLAS leaf's pop test (tlas.rs:80-83), made when the instance's first leaf comes up
+                    if (c.z != r_inst) { r_inst = c.z; r_pruned = asf(c.w) > t_max; }
+                    if (!r_pruned && !(t_est > t_max))         // the leaf's own pop test  blas.rs:222-225
+                    {
+#if PT_STEP_STATS
+                        st_lane_test += 1u;
+#endif
+                        uint32_t first, count;
+                        leaf_range(bl, c.x >> NODE_KIND_SHIFT, c.x & NODE_PAYLOAD_MASK, first, count);
+                        const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
+                        const float t_min = PT_EPSILON - t_est;
+                        const uint32_t c_inst = c.z;
+                        auto accept = [&](const TriEval& e, uint32_t tri) {
+                            if (e.uv_ok && tri_in_range(e, t_min, t_max - t_est))
+                            {
+                                bt = e.td / e.det + t_est;     // primitive.rs:158-170
+                                hud = e.ud;
+                                hvd = e.vd;
+                                hdet = e.det;
+                                t_max = bt;
+                                bid = (c_inst << prim_bits) | tri;
+                            }
+                        };
+                        uint32_t k = 0;
+                        for (; k + 1u < count; k += 2u)
+                        {
+                            const uint4* tp = bl.tris + 3u * (first + k);
+                            const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
+                            accept(ea, first + k);
+                            accept(eb, first + k + 1u);
+                        }
+                        if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
+                        if (bt != bt) { sp = stk.empty(); in_blas = false; head = tail; parked = false; } // NaN t_max: nothing else can be accepted anywhere
+                    }
+                }
+                PT_TT_END(tt_leaf);
+            }
+            else if (mb != 0ull)
+            {
+                // ---- branch step
+#if PT_STEP_STATS
+                if (lane_id() == (uint32_t)__builtin_ctzll(mb)) st_wave_branch += 1u;
+                st_lane_branch += can_b ? 1u : 0u;
+#endif
+                if (can_b)
+                {
+                    sp = stk.down(sp);
+                    const uint2 e = stk.get(sp);
+                    uint32_t link = e.x;
+                    float ts = asf(e.y);
+                    bool go = !(ts > t_max);                         // tlas.rs:80-83 / blas.rs:222-225 with a t_max that is not smaller than the reference's
+                    if (go && (link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+                    {
+                        if (!IDENT && head != tail) { sp = stk.up(sp); parked = true; go = false; } // the FIFO's entries still need the old object-space ray
+                        else
+                        {
+                            inst = link & NODE_PAYLOAD_MASK;
+                            ts_inst = ts;
+                            uint32_t blas_root;
+                            if (IDENT) blas_root = bl.inst[7u * inst + 6u].x;
+                            else ob = to_object(bl, inst, w, ray_finite, blas_root);
+                            in_blas = true;
+                            blas_base = sp;
+                            link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3]; // blas.rs:217: the root goes in with t_enter 0, no box test
+                            ts = 0.0f;
+                        }
+                    }
+                    if (go)
+                    {
+                        uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+                        if (kind & 1u) { ring.put(tail, make_uint4(link, asu(ts), inst, asu(ts_inst))); tail += 1u; } // a leaf that was the farther child, or a BLAS that is one leaf
+#pragma unroll 1
+                        for (int lvl = 0; lvl < PT_BRANCH_LEVELS2 && kind == NODE_BRANCH; ++lvl)
+                        {
+                            const uint4* cp = bl.nodes + 2u * payload;
+                            const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
+                            const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
+                            float tl, tr;
+                            const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                            const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                            kind = NODE_INSTANCE; // nothing more in this step unless the nearer child is a branch
+                            if (hl || hr)
+                            {
+                                // push_to_stack  blas.rs:133-162: the farther child underneath (ties: left underneath, right popped first)
+                                const bool both = hl && hr, left_near = hl && (tl < tr || !hr);
+                                const uint2 near = left_near ? make_uint2(l0.w, asu(tl)) : make_uint2(r0.w, asu(tr));
+                                const uint2 far = left_near ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
+                                const uint32_t nk = near.x >> NODE_KIND_SHIFT;
+                                if (nk & 1u)
+                                {
+                                    // the nearer child is a leaf: it is what the reference pops next
+                                    ring.put(tail, make_uint4(near.x, near.y, inst, asu(ts_inst)));
+                                    tail += 1u;
+                                    if (both)
+                                    {
+                                        // ... and if the farther one is a leaf too it is popped right after it
+                                        if ((far.x >> NODE_KIND_SHIFT) & 1u) { ring.put(tail, make_uint4(far.x, far.y, inst, asu(ts_inst))); tail += 1u; }
+                                        else { stk.put(sp, far); sp = stk.up(sp); }
+                                    }
+                                }
+                                else
+                                {
+                                    if (both) { stk.put(sp, far); sp = stk.up(sp); }
+                                    if (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS2) { kind = NODE_BRANCH; payload = near.x & NODE_PAYLOAD_MASK; }
+                                    else { stk.put(sp, near); sp = stk.up(sp); }
+                                }
+                            }
+                        }
+                    }
+                }
+                PT_TT_END(tt_branch);
+            }
+            else break; // every lane that had a ray has just finished it
+        }
+    }
+#if PT_STEP_STATS == 2
+    {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        const uint64_t tt_total = __builtin_readcyclecounter() - tt_start;
+        if (lane_id() == 0u)
+        {
+            atomicAdd(line + 16, n_service); atomicAdd(line + 17, (uint32_t)(tt_service >> 6)); atomicAdd(line + 18, (uint32_t)(tt_branch >> 6));
+            atomicAdd(line + 19, (uint32_t)(tt_leaf >> 6)); atomicAdd(line + 20, (uint32_t)(tt_total >> 6));
+        }
+    }
+#endif
+    if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
+    {
+        const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
+        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) out.q_term[i] = make_uint2(HOLE, 0u);
+#pragma unroll
+        for (uint32_t c = 1; c < Q_COUNT; ++c)
+        {
+            f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride;
+            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
+        }
+    }
+#if PT_STEP_STATS
+    // words 8..15 of the cursor lines: wave-steps, lanes holding a ray in them, lanes expanding a branch, lanes taking a candidate, lanes
+    // testing triangles, wave-steps that were branch steps / leaf rounds, lanes that could do neither (tools/step_stats.py)
+    {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        if (lane_id() == 0u) { atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); atomicAdd(line + 15, st_lane_park); }
+        uint32_t a = st_lane_branch, b = st_lane_leaf, c2 = st_lane_test;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c2 += __shfl_xor(c2, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 10, a); atomicAdd(line + 11, b); atomicAdd(line + 12, c2); }
+        a = st_wave_branch; b = st_wave_leaf;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 13, a); atomicAdd(line + 14, b); }
+    }
+#endif
+    if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
+}
+
 // ------------------------------------------------------------------------------------------------ any hit
 enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 
@@ -2006,10 +2449,10 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
     o[8] = (float)(rng.k - draws);
 }
 
-size_t trace_lds_bytes(const TraceLaunch& tl)
+size_t trace_lds_bytes(const TraceLaunch& tl, bool with_cands = false)
 {
     const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
-    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8;
+    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8 + (with_cands ? (size_t)PT_CAND_SLOTS * tl.block_threads * 16 : 0);
 }
 
 } // namespace
@@ -2053,11 +2496,35 @@ template <int MODE>
 static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t cap_in,
                                 uint32_t* heads, const ClosestOut& out)
 {
-    const size_t lds = trace_lds_bytes(tl);
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
     const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
 #define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, out)
+#if PT_TWO_PHASE
+    // closest hit with deferred leaves (k_closest2); it relies on nested boxes, which the host has checked (SceneView::trav_flags)
+    if constexpr (MODE != CLOSEST_LIGHTS)
+    {
+        if (tl.scene.trav_flags & TRAV_NESTED_BOXES)
+        {
+            const size_t lds = trace_lds_bytes(tl, true);
+            const bool ident = (tl.scene.trav_flags & TRAV_ALL_IDENTITY) != 0u;
+            const int sel = (tl.lds_scene ? 4 : 0) | (spill ? 2 : 0) | (ident ? 1 : 0);
+            switch (sel)
+            {
+            case 7: PT_LAUNCH((k_closest2<true, MODE, true, true>)); break;
+            case 6: PT_LAUNCH((k_closest2<true, MODE, true, false>)); break;
+            case 5: PT_LAUNCH((k_closest2<true, MODE, false, true>)); break;
+            case 4: PT_LAUNCH((k_closest2<true, MODE, false, false>)); break;
+            case 3: PT_LAUNCH((k_closest2<false, MODE, true, true>)); break;
+            case 2: PT_LAUNCH((k_closest2<false, MODE, true, false>)); break;
+            case 1: PT_LAUNCH((k_closest2<false, MODE, false, true>)); break;
+            default: PT_LAUNCH((k_closest2<false, MODE, false, false>)); break;
+            }
+            return;
+        }
+    }
+#endif
+    const size_t lds = trace_lds_bytes(tl);
     if (tl.lds_scene && !spill) PT_LAUNCH((k_closest<true, MODE, false>));
     else if (tl.lds_scene) PT_LAUNCH((k_closest<true, MODE, true>));
     else if (!spill) PT_LAUNCH((k_closest<false, MODE, false>));

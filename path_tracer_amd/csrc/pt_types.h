@@ -125,7 +125,18 @@ struct SceneView
     uint32_t stack_entries;           // per-lane traversal stack capacity (exact bound)
     uint32_t stack_lds;               // closest-hit levels kept in LDS; deeper levels spill to `stack_spill` (deep BLASes only)
     uint64_t* stack_spill;            // 8-byte (node, t_enter) records [level - stack_lds][global lane], null when stack_entries <= stack_lds
+    uint32_t trav_flags;              // TRAV_*
 };
+// what the host found out about the trees (pt_scene.cpp: flatten)
+enum : uint32_t
+{
+    TRAV_ALL_IDENTITY = 1u, // every instance of both TLASes is the identity: one object-space image of a ray serves all of them
+    TRAV_NESTED_BOXES = 2u  // every child's box lies inside its parent's (bit for bit): box entry distances never decrease downwards
+};
+// FIFO entries per lane of the closest-hit kernel with deferred leaves (k_closest2): 16 bytes each in LDS; power of two
+#ifndef PT_CAND_SLOTS
+#define PT_CAND_SLOTS 4
+#endif
 
 struct CameraView
 {

@@ -67,6 +67,9 @@ namespace {
 #ifndef PT_TWO_PHASE
 #define PT_TWO_PHASE 0
 #endif
+#ifndef PT_SORT_RETIRE
+#define PT_SORT_RETIRE 0
+#endif
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
@@ -1602,6 +1605,495 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
 }
 
+// ------------------------------------------------------------------------------------------------ closest hit, leaves deferred, lanes streamed
+// k_closest2's wave-steps are uniform, but its lanes are not busy: a ray's set-up (three divisions, the root box, the object-space image)
+// and its retirement (two divisions, the class's queue slot, 48 bytes of stores) are expensive, so they are done for many lanes at a
+// time — which means waiting until many lanes are idle: 43 of 64 lanes hold a ray on average, 35 do work in a step, and the service runs
+// with ~24 lanes (tools/step_stats2.py: 27 % of the wave time is service, 64 % steps).  Here every lane has two more sets of registers:
+//   * a NEXT ray, already set up (origin, direction, reciprocal, t_max, indices, whether it meets the root box), and
+//   * the RESULT of the ray it finished last (t, the (u, v) numerators and determinant, hit id, indices).
+// A lane that finishes its ray parks the result, takes its next ray and goes on within one wave-step.  Set-up runs as a batch when
+// PT_STREAM_IN lanes have no next ray, retirement as a batch when PT_STREAM_OUT lanes hold a result (or a lane with a result in hand
+// finishes another ray): both at 60–100 % lane occupancy instead of 37 %, and the steps in between run with the lanes full.
+// What the retirement needs of the ray itself (direction, origin) it reads back from the ray queue by ray index.
+// Everything the service sections need of the launch description is read through the kernel-argument segment when they run
+// (s_load, scalar cache) instead of living in scalar registers across the traversal loop (k_closest2 spills 71 of them).
+#ifndef PT_STREAM_IN
+#define PT_STREAM_IN 32
+#endif
+#ifndef PT_STREAM_OUT
+#define PT_STREAM_OUT 40
+#endif
+#ifndef PT_STREAM_STEPS
+#define PT_STREAM_STEPS 2   // wave-steps between two looks at the lanes' buffers
+#endif
+struct ClosestKArgs
+{
+    SceneView sv;
+    const uint4* gblob;
+    const f4* ra;
+    const f4* rb;
+    const uint32_t* n_ptr;
+    uint32_t* heads;
+    uint32_t root, cap_in;
+    ClosestOut out;
+};
+typedef const __attribute__((address_space(4))) ClosestKArgs* ClosestKArgsPtr;
+// the kernel's single argument as it lies in the kernel-argument segment; the empty asm keeps the compiler from hoisting the loads
+// made through the pointer out of the section that makes them
+__device__ __forceinline__ ClosestKArgsPtr cold_args()
+{
+    ClosestKArgsPtr p = (ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <bool LDS_SCENE, int MODE, bool SPILL, bool IDENT>
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest3(const ClosestKArgs a)
+{
+    static_assert(MODE != CLOSEST_LIGHTS, "the fused NEE chain stays on k_closest");
+    extern __shared__ uint4 smem[];
+    const FetchPlan plan = fetch_plan(min(*a.n_ptr, a.cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
+    if (blockIdx.x >= plan.blocks) return;
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
+    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, a.sv);
+    const CandRing ring = CandRing::make(smem, blob_words, a.sv);
+    const uint32_t prim_bits = a.sv.prim_bits;
+    uint32_t* const heads = a.heads;
+
+    // the ray in flight
+    bool active = false, ray_finite = false, in_blas = false, parked = false, r_pruned = false;
+    uint32_t ray_idx = 0, pid = 0;
+    LaneRay w{}, ob{};
+    float t_max = 0.0f, bt = 0.0f, ts_inst = 0.0f;
+    float hud = 0.0f, hvd = 0.0f, hdet = 1.0f;
+    uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0, r_inst = MISS_ID;
+    uint32_t head = 0, tail = 0;
+    // the next ray, set up
+    bool nx_valid = false;
+    LaneRay nx{};
+    float nx_tmax = 0.0f;
+    uint32_t nx_ridx = 0, nx_pid = 0, nx_flags = 0; // flags: bit 0 the ray meets the root box, bit 1 origin and direction are finite
+    // the last result
+    bool res_valid = false;
+    uint32_t res_ridx = 0, res_pid = 0, res_bid = MISS_ID;
+    float res_bt = 0.0f, res_hud = 0.0f, res_hvd = 0.0f, res_hdet = 1.0f;
+
+    WaveRange wr = first_range(plan, heads);
+    uint32_t valid_rays = 0;
+#if PT_STEP_STATS
+    uint32_t st_iter = 0, st_lane_active = 0, st_lane_branch = 0, st_lane_leaf = 0, st_lane_test = 0, st_wave_branch = 0, st_wave_leaf = 0, st_lane_park = 0;
+    uint32_t st_n_out = 0, st_lanes_out = 0, st_n_in = 0, st_lanes_in = 0, st_bound = 0;
+#endif
+    Region bin_region[Q_COUNT];
+#pragma unroll
+    for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
+    uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (;;)
+    {
+        // ---- look at the lanes' buffers
+        bool fin = false;
+        if (active)
+        {
+            if (in_blas && sp == blas_base) in_blas = false;   // BLAS::intersect returned  blas.rs:255
+            fin = sp == stk.empty() && head == tail;
+        }
+        auto park_result = [&]() {
+            res_ridx = ray_idx; res_pid = pid; res_bt = bt; res_hud = hud; res_hvd = hvd; res_hdet = hdet; res_bid = bid;
+            res_valid = true;
+            active = false;
+        };
+        if (fin && !res_valid) { park_result(); fin = false; }
+        const uint64_t m_stuck = __ballot(fin);      // finished, but the result of the ray before is still in hand
+        const uint64_t m_res = __ballot(res_valid);
+        const bool no_more = wr.drained && wr.cur >= wr.end;
+        uint64_t m_nx = __ballot(nx_valid);
+        const uint64_t m_act = __ballot(active);
+#if PT_STEP_STATS
+        st_bound += 1u;
+#endif
+        if (m_res != 0ull && (m_stuck != 0ull || (uint32_t)__popcll(m_res) >= (uint32_t)PT_STREAM_OUT || (m_act == 0ull && (no_more || m_nx == 0ull))))
+        {
+            // ---- retirement batch (the logic of k_closest's retire section, on the parked results)
+#if PT_STEP_STATS
+            st_n_out += 1u; st_lanes_out += (uint32_t)__popcll(m_res);
+#endif
+            const ClosestKArgsPtr k = cold_args();
+            bool pending = res_valid;
+            f3 rd{0.0f, 0.0f, 0.0f}, ro{0.0f, 0.0f, 0.0f};
+            if (pending)
+            {
+                rd = xyz(a.rb[res_ridx]);
+                if (MODE == CLOSEST_PRIMARY) ro = f3{k->out.eye.x, k->out.eye.y, k->out.eye.z};
+                else if (MODE == CLOSEST_WORLD) ro = xyz(a.ra[res_ridx]);
+            }
+            if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
+            {
+                const uint32_t finalize_miss = k->out.finalize_miss;
+                uint64_t qm = m_res;
+                if (MODE == CLOSEST_PRIMARY)
+                {
+                    uint8_t* const occl = k->out.occl;
+                    const bool missed = pending && res_bid == MISS_ID && finalize_miss != 0u;
+                    if (pending) occl[res_ridx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
+                    if (pending && res_bid == MISS_ID)
+                    {
+                        // defaults of integrator.rs:156-157 (with an environment map the terminal pass shades the miss)
+                        const uint32_t keep_id_from = k->out.keep_id_from, keep_pos_from = k->out.keep_pos_from;
+                        if (res_ridx >= keep_id_from) k->out.first_id[res_ridx - keep_id_from] = 255u;
+                        if (res_ridx >= keep_pos_from)
+                        {
+                            const f3 far = fma3(rd, bc3(1e5f), ro);
+                            k->out.first_pos[res_ridx - keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
+                        }
+                    }
+                    qm = __ballot(pending && !missed);
+                    pending = pending && !missed;
+                }
+                if (MODE == CLOSEST_WORLD)
+                {
+                    // paths that end at this hit or miss are finished here (integrator.rs:207-214, 263-266): see k_closest
+                    bool ends = false, emissive = false;
+                    uint32_t mat_id = 0;
+                    if (pending)
+                    {
+                        if (res_bid == MISS_ID) ends = finalize_miss != 0u;
+                        else
+                        {
+                            const uint4 meta = bl.inst[7u * (res_bid >> prim_bits) + 6u];
+                            emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
+                            mat_id = meta.z;
+                        }
+                    }
+                    if (__ballot(ends) != 0ull)
+                    {
+                        const DPathRec* const recs = k->out.rec;
+                        const uint32_t enable_nee = k->out.enable_nee;
+                        if (ends)
+                        {
+                            const DPathRec& rec = recs[res_pid];
+                            const f4 acc4 = rec.acc;
+                            const uint32_t flags = asu(acc4.w);
+                            if (!(flags & FLAG_BSDF_CAST))
+                            {
+                                f3 acc = xyz(acc4);
+                                if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
+                                const f3 pw = xyz(rec.pw);
+                                if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
+                                else if (!enable_nee || (flags & FLAG_LAST_DELTA))
+                                {
+                                    const DMaterial& m = a.sv.materials[mat_id];
+                                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
+                                }
+                                k->out.radiance[res_pid] = f4{acc.x, acc.y, acc.z, 0.0f};
+                                pending = false;
+                            }
+                        }
+                    }
+                    qm = __ballot(pending);
+                }
+                if (qm != 0ull)
+                {
+                    uint32_t cls = Q_COUNT;
+                    if (pending) cls = res_bid != MISS_ID ? (bl.inst[7u * (res_bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
+                    const f4 hit{res_bt, res_hud / res_hdet, res_hvd / res_hdet, asf(res_bid)};
+                    const uint32_t class_mask = k->out.class_mask, q_stride = k->out.q_stride, q_class_slot = k->out.q_class_slot;
+                    const Stripes stripes = stripes_for(plan.n);
+#pragma unroll
+                    for (uint32_t c = 0; c < Q_COUNT; ++c)
+                    {
+                        if (!((class_mask >> c) & 1u)) continue;
+                        const uint64_t m = __ballot(cls == c);
+                        if (m == 0ull) continue;
+                        Placement pl;
+                        if (c == Q_TERMINAL)
+                        {
+                            const uint32_t rsize = finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
+                            pl = wave_reserve(bin_region[c], k->out.n_shade + c, (uint32_t)__popcll(m), rsize, k->out.cap_term, k->out.overflow);
+                        }
+                        else pl = wave_reserve_striped(bin_region[c], k->out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), k->out.cap_shade, k->out.overflow);
+                        uint32_t my_rank = mbcnt64(m);
+#if PT_SORT_RETIRE
+                        // experiment: slots in ray-index order instead of lane order
+                        {
+                            my_rank = 0u;
+                            for (uint64_t mm = m; mm != 0ull; mm &= mm - 1ull)
+                            {
+                                const uint32_t other = __builtin_amdgcn_readlane(res_ridx, (int)__builtin_ctzll(mm));
+                                my_rank += other < res_ridx ? 1u : 0u;
+                            }
+                        }
+#endif
+                        if (cls == c)
+                        {
+                            const uint32_t pos = place(pl, my_rank);
+                            if (c == Q_TERMINAL)
+                            {
+                                k->out.hits[res_ridx] = hit;
+                                k->out.q_term[pos] = make_uint2(res_ridx, res_pid);
+                            }
+                            else
+                            {
+                                f4* const qa = k->out.q_base + (size_t)(3u * ((q_class_slot >> (4u * c)) & 0xfu)) * q_stride + pos;
+                                nt_store(qa, f4{rd.x, rd.y, rd.z, asf(res_pid)});
+                                nt_store(qa + q_stride, hit);
+                                if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)q_stride, f4{ro.x, ro.y, ro.z, 0.0f});
+                            }
+                        }
+                    }
+                }
+            }
+            else
+            {
+                if (pending) k->out.hits[res_ridx] = f4{res_bt, res_hud / res_hdet, res_hvd / res_hdet, asf(res_bid)};
+            }
+            res_valid = false;
+            if (fin) park_result();   // the lanes that were waiting for their result registers
+        }
+        // ---- set-up batch: next rays for the lanes that have none
+        if (!no_more && ((uint32_t)__popcll(~m_nx) >= (uint32_t)PT_STREAM_IN || __ballot(active) == 0ull))
+        {
+            const uint64_t need = ~m_nx;
+            uint32_t first;
+            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(need), first);
+            const uint32_t rank = mbcnt64(need);
+#if PT_STEP_STATS
+            st_n_in += 1u; st_lanes_in += take;
+#endif
+            if (!nx_valid && rank < take)
+            {
+                const uint32_t mine = first + rank;
+                const f4 b = a.rb[mine];
+                nx_ridx = mine;
+                nx_pid = asu(b.w);
+                if (nx_pid != HOLE)
+                {
+                    valid_rays += 1u;
+                    if (MODE == CLOSEST_PRIMARY)
+                    {
+                        const ClosestKArgsPtr k = cold_args();
+                        nx.o = f3{k->out.eye.x, k->out.eye.y, k->out.eye.z};
+                        nx_tmax = asf(0x7f800000u);
+                    }
+                    else
+                    {
+                        const f4 ao = a.ra[mine];
+                        nx.o = xyz(ao);
+                        nx_tmax = ao.w;
+                    }
+                    nx.d = xyz(b);
+                    nx.inv = rcp3(nx.d);
+                    const bool finite = finite3(nx.o) && finite3(nx.d);
+                    float te;
+                    const uint4 root0 = bl.nodes[2u * a.root];
+                    const bool ok = (nx_tmax == nx_tmax) && slab(root0, bl.nodes[2u * a.root + 1u], nx.o, nx.inv, nx_tmax, te); // tlas.rs:68-72
+                    nx_flags = (ok ? 1u : 0u) | (finite ? 2u : 0u);
+                    nx_valid = true;
+                }
+            }
+        }
+        // ---- a lane without a ray takes its next one
+        if (!active && nx_valid)
+        {
+            ray_idx = nx_ridx;
+            pid = nx_pid;
+            w = nx;
+            t_max = nx_tmax;
+            ray_finite = (nx_flags & 2u) != 0u;
+            bid = MISS_ID;
+            bt = asf(0x7f800000u);
+            hud = 0.0f;
+            hvd = 0.0f;
+            hdet = 1.0f;
+            in_blas = false;
+            parked = false;
+            r_inst = MISS_ID;
+            head = tail = 0u;
+            sp = stk.empty();
+            if (nx_flags & 1u)
+            {
+                stk.put(sp, make_uint2(reinterpret_cast<const uint32_t*>(bl.nodes + 2u * a.root)[3], 0u)); // tlas.rs:74: the root goes in with t_enter 0
+                sp = stk.up(sp);
+                // every instance is the identity: one object-space image of the ray serves them all (instance 0's matrix is everybody's)
+                if (IDENT) { uint32_t unused; ob = to_object(bl, 0u, w, ray_finite, unused); }
+            }
+            active = true;
+            nx_valid = false;
+        }
+        if (__ballot(active || nx_valid || res_valid) == 0ull)
+        {
+            if (no_more) break;
+            continue; // (a set-up batch that brought nothing but holes)
+        }
+
+#pragma unroll 1
+        for (int it = 0; it < PT_STREAM_STEPS; ++it)
+        {
+            if (it != 0 && active && in_blas && sp == blas_base) in_blas = false;
+            const bool has_c = active && head != tail;
+            const bool can_b = active && sp != stk.empty() && !parked && (tail - head) <= (uint32_t)(PT_CAND_SLOTS - 2);
+            const uint64_t ml = __ballot(has_c), mb = __ballot(can_b);
+#if PT_STEP_STATS
+            if ((ml | mb) != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(__ballot(active)); st_lane_park += (uint32_t)__popcll(__ballot(active && !has_c && !can_b)); }
+#endif
+            if (ml != 0ull && ((uint32_t)__popcll(ml) >= (uint32_t)PT_LEAF_VOTE || mb == 0ull))
+            {
+                // ---- leaf round (k_closest2)
+#if PT_STEP_STATS
+                if (lane_id() == (uint32_t)__builtin_ctzll(ml)) st_wave_leaf += 1u;
+                st_lane_leaf += has_c ? 1u : 0u;
+#endif
+                if (has_c)
+                {
+                    const uint4 c = ring.get(head);
+                    head += 1u;
+                    if (head == tail) parked = false;
+                    const float t_est = asf(c.y);
+                    if (c.z != r_inst) { r_inst = c.z; r_pruned = asf(c.w) > t_max; }   // the TLAS leaf's pop test  tlas.rs:80-83
+                    if (!r_pruned && !(t_est > t_max))                                    // the leaf's own  blas.rs:222-225
+                    {
+#if PT_STEP_STATS
+                        st_lane_test += 1u;
+#endif
+                        uint32_t first, count;
+                        leaf_range(bl, c.x >> NODE_KIND_SHIFT, c.x & NODE_PAYLOAD_MASK, first, count);
+                        const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
+                        const float t_min = PT_EPSILON - t_est;
+                        const uint32_t c_inst = c.z;
+                        auto accept = [&](const TriEval& e, uint32_t tri) {
+                            if (e.uv_ok && tri_in_range(e, t_min, t_max - t_est))
+                            {
+                                bt = e.td / e.det + t_est;     // primitive.rs:158-170
+                                hud = e.ud;
+                                hvd = e.vd;
+                                hdet = e.det;
+                                t_max = bt;
+                                bid = (c_inst << prim_bits) | tri;
+                            }
+                        };
+                        uint32_t kk = 0;
+                        for (; kk + 1u < count; kk += 2u)
+                        {
+                            const uint4* tp = bl.tris + 3u * (first + kk);
+                            const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
+                            accept(ea, first + kk);
+                            accept(eb, first + kk + 1u);
+                        }
+                        if (kk < count) accept(tri_eval(bl.tris + 3u * (first + kk), mo, ob.d), first + kk);
+                        if (bt != bt) { sp = stk.empty(); in_blas = false; head = tail; parked = false; } // NaN t_max: nothing else can be accepted anywhere
+                    }
+                }
+            }
+            else if (mb != 0ull)
+            {
+                // ---- branch step (k_closest2)
+#if PT_STEP_STATS
+                if (lane_id() == (uint32_t)__builtin_ctzll(mb)) st_wave_branch += 1u;
+                st_lane_branch += can_b ? 1u : 0u;
+#endif
+                if (can_b)
+                {
+                    sp = stk.down(sp);
+                    const uint2 e = stk.get(sp);
+                    uint32_t link = e.x;
+                    float ts = asf(e.y);
+                    bool go = !(ts > t_max);
+                    if (go && (link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+                    {
+                        if (!IDENT && head != tail) { sp = stk.up(sp); parked = true; go = false; }
+                        else
+                        {
+                            inst = link & NODE_PAYLOAD_MASK;
+                            ts_inst = ts;
+                            uint32_t blas_root;
+                            if (IDENT) blas_root = bl.inst[7u * inst + 6u].x;
+                            else ob = to_object(bl, inst, w, ray_finite, blas_root);
+                            in_blas = true;
+                            blas_base = sp;
+                            link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3];
+                            ts = 0.0f;
+                        }
+                    }
+                    if (go)
+                    {
+                        uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+                        if (kind & 1u) { ring.put(tail, make_uint4(link, asu(ts), inst, asu(ts_inst))); tail += 1u; }
+#pragma unroll 1
+                        for (int lvl = 0; lvl < PT_BRANCH_LEVELS2 && kind == NODE_BRANCH; ++lvl)
+                        {
+                            const uint4* cp = bl.nodes + 2u * payload;
+                            const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
+                            const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
+                            float tl, tr;
+                            const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                            const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                            kind = NODE_INSTANCE;
+                            if (hl || hr)
+                            {
+                                const bool both = hl && hr, left_near = hl && (tl < tr || !hr);
+                                const uint2 near = left_near ? make_uint2(l0.w, asu(tl)) : make_uint2(r0.w, asu(tr));
+                                const uint2 far = left_near ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
+                                const uint32_t nk = near.x >> NODE_KIND_SHIFT;
+                                if (nk & 1u)
+                                {
+                                    ring.put(tail, make_uint4(near.x, near.y, inst, asu(ts_inst)));
+                                    tail += 1u;
+                                    if (both)
+                                    {
+                                        if ((far.x >> NODE_KIND_SHIFT) & 1u) { ring.put(tail, make_uint4(far.x, far.y, inst, asu(ts_inst))); tail += 1u; }
+                                        else { stk.put(sp, far); sp = stk.up(sp); }
+                                    }
+                                }
+                                else
+                                {
+                                    if (both) { stk.put(sp, far); sp = stk.up(sp); }
+                                    if (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS2) { kind = NODE_BRANCH; payload = near.x & NODE_PAYLOAD_MASK; }
+                                    else { stk.put(sp, near); sp = stk.up(sp); }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            else break; // every lane's ray is finished: back to the buffers
+        }
+    }
+    if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
+    {
+        const ClosestKArgsPtr k = cold_args();
+        const uint32_t q_stride = k->out.q_stride, q_class_slot = k->out.q_class_slot;
+        const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
+        uint2* const q_term = k->out.q_term;
+        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) q_term[i] = make_uint2(HOLE, 0u);
+#pragma unroll
+        for (uint32_t c = 1; c < Q_COUNT; ++c)
+        {
+            f4* const qa = k->out.q_base + (size_t)(3u * ((q_class_slot >> (4u * c)) & 0xfu)) * q_stride;
+            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
+        }
+    }
+#if PT_STEP_STATS
+    {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        if (lane_id() == 0u)
+        {
+            atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); atomicAdd(line + 15, st_lane_park);
+            atomicAdd(line + 16, st_n_out); atomicAdd(line + 17, st_lanes_out); atomicAdd(line + 18, st_n_in); atomicAdd(line + 19, st_lanes_in); atomicAdd(line + 20, st_bound);
+        }
+        uint32_t x = st_lane_branch, y = st_lane_leaf, z = st_lane_test;
+        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); z += __shfl_xor(z, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 10, x); atomicAdd(line + 11, y); atomicAdd(line + 12, z); }
+        x = st_wave_branch; y = st_wave_leaf;
+        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 13, x); atomicAdd(line + 14, y); }
+    }
+#endif
+    if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
+}
+
 // ------------------------------------------------------------------------------------------------ any hit
 enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 
@@ -2509,6 +3001,23 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
             const size_t lds = trace_lds_bytes(tl, true);
             const bool ident = (tl.scene.trav_flags & TRAV_ALL_IDENTITY) != 0u;
             const int sel = (tl.lds_scene ? 4 : 0) | (spill ? 2 : 0) | (ident ? 1 : 0);
+#if PT_TWO_PHASE == 2
+            const ClosestKArgs ka{tl.scene, blob, rq.a, rq.b, n_ptr, heads, root, cap_in, out};
+#define PT_LAUNCH3(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
+            switch (sel)
+            {
+            case 7: PT_LAUNCH3((k_closest3<true, MODE, true, true>)); break;
+            case 6: PT_LAUNCH3((k_closest3<true, MODE, true, false>)); break;
+            case 5: PT_LAUNCH3((k_closest3<true, MODE, false, true>)); break;
+            case 4: PT_LAUNCH3((k_closest3<true, MODE, false, false>)); break;
+            case 3: PT_LAUNCH3((k_closest3<false, MODE, true, true>)); break;
+            case 2: PT_LAUNCH3((k_closest3<false, MODE, true, false>)); break;
+            case 1: PT_LAUNCH3((k_closest3<false, MODE, false, true>)); break;
+            default: PT_LAUNCH3((k_closest3<false, MODE, false, false>)); break;
+            }
+#undef PT_LAUNCH3
+            return;
+#endif
             switch (sel)
             {
             case 7: PT_LAUNCH((k_closest2<true, MODE, true, true>)); break;

@@ -318,3 +318,9 @@ if __name__ == "__main__":
               f"({c['p2_lanes'] / max(c['p2'], 1):.1f} lanes, {c['p2_tested'] / max(c['p2'], 1):.1f} testing); model VALU/ray {c['valu'] / c['rays']:.1f}")
     random.seed(1)
     c = run_r2(2, 4) if False else None
+    print("streaming (lanes refilled at every step / every 2 steps):")
+    for T, C, lv, se in ((24, 4, 2, 1), (32, 4, 2, 1), (40, 4, 2, 1), (32, 4, 2, 2), (40, 4, 2, 2), (48, 4, 2, 2), (40, 4, 1, 2)):
+        random.seed(1)
+        c = run_q(2, lv, T, C, refill_below=63, service_every=se)
+        print(f"voted T={T} C={C} levels={lv} refill every {se}: {c['rays']} rays, branch steps {c['p1']} ({c['p1_lanes'] / max(c['p1'], 1):.1f} lanes), leaf steps {c['p2']} "
+              f"({c['p2_lanes'] / max(c['p2'], 1):.1f} lanes, {c['p2_tested'] / max(c['p2'], 1):.1f} testing); steps/ray {(c['p1'] + c['p2']) / c['rays']:.3f}")

@@ -34,8 +34,12 @@ print(f"\nPer ray: {lb / rays_tot:.2f} branch steps, {ll / rays_tot:.2f} candida
 
 os.environ["PTMI_STEP_STATS_BASE"] = "16"
 tt = r.last_batch_step_stats().astype(np.float64).sum(axis=0)
-if tt[4] > 0:
+if tt[4] > 0 and tt[4] > tt[0] * 100:   # k_closest2, PT_STEP_STATS=2 build: section times
     n_service, t_service, t_branch, t_leaf, t_total = tt[:5]
     print(f"\nWave time by section (PT_STEP_STATS=2 build): service {t_service / t_total:.3f} ({n_service / 1e6:.2f} M services, {64 * t_service / max(n_service, 1):.0f} ticks each), "
           f"branch steps {t_branch / t_total:.3f} ({64 * t_branch / max(wb, 1):.0f} ticks each), leaf rounds {t_leaf / t_total:.3f} ({64 * t_leaf / max(wl, 1):.0f} ticks each), "
           f"rest {1 - (t_service + t_branch + t_leaf) / t_total:.3f}; rays per service {rays_tot / max(n_service, 1):.1f}")
+elif tt[4] > 0:                          # k_closest3: batches
+    n_out, lanes_out, n_in, lanes_in, bound = tt[:5]
+    print(f"\nStreamed lanes (k_closest3): {bound / 1e6:.2f} M looks at the buffers ({it / bound:.2f} wave-steps between two), {n_out / 1e6:.3f} M retirement batches of {lanes_out / max(n_out, 1):.1f} lanes, "
+          f"{n_in / 1e6:.3f} M set-up batches of {lanes_in / max(n_in, 1):.1f} rays")

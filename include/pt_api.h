@@ -147,6 +147,12 @@ int pt_reset_accumulation(pt_ctx* ctx);
  * gather) can read it without a host round trip; *n_pixels = local pixel count */
 int pt_accum_device_ptr(pt_ctx* ctx, void** dev_ptr, uint64_t* n_pixels);
 int pt_read_accumulation(pt_ctx* ctx, float* data_rgba);
+/* accumulation, last sample's first-hit position and id history as they lie on the device (any pointer may be NULL), e.g. after pt_render_device */
+int pt_read_frame(pt_ctx* ctx, float* data_rgba, float* position_xyzt, uint32_t* id);
+/* checkpoint / resume across contexts and processes (the progressive accumulation of src/shaders/accumulate.wgsl:20-23):
+ * restores what pt_render / pt_read_frame returned — accumulation, and optionally (NULL = leave alone) the last sample's first-hit position and the
+ * id history — so that pt_render(first_sample = samples already in `data_rgba`, ...) continues the frame bit for bit */
+int pt_write_accumulation(pt_ctx* ctx, const float* data_rgba, const float* position_xyzt, const uint32_t* id);
 /* per-sample radiance (rgb,1) of the last pt_render* call's final batch is not kept; this renders n_samples and
  * writes them un-accumulated: out[(s * local_pixels + pixel) * 4] (test hook for bit-exact comparison per sample) */
 int pt_render_samples(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples, float* samples_rgba);

@@ -194,6 +194,15 @@ public:
     // n_samples per pixel accumulated without the temporal pass (what the loop converges to for a camera at rest)
     void render(uint32_t first_sample, uint32_t n_samples) { check(pt_render_device(ctx_, first_sample, n_samples)); check(pt_synchronize(ctx_)); }
     void reset_accumulation() { check(pt_reset_accumulation(ctx_)); }
+    Frame read_frame() const
+    {
+        Frame f;
+        f.data.resize((size_t)width_ * height_ * 4); f.position.resize((size_t)width_ * height_ * 4); f.id.resize((size_t)width_ * height_);
+        check(pt_read_frame(ctx_, f.data.data(), f.position.data(), f.id.data()));
+        return f;
+    }
+    // checkpoint / resume: put a frame's state (as frame() / pt_render returned it) back, e.g. in another process
+    void write_accumulation(const Frame& f) { check(pt_write_accumulation(ctx_, f.data.data(), f.position.empty() ? nullptr : f.position.data(), f.id.empty() ? nullptr : f.id.data())); }
     std::vector<float> present() const { std::vector<float> v((size_t)width_ * height_ * 4); check(pt_present(ctx_, v.data())); return v; }
     std::vector<uint8_t> present_rgb8() const { std::vector<uint8_t> v((size_t)width_ * height_ * 3); check(pt_present_rgb8(ctx_, v.data())); return v; }
     void write_image(const std::string& path) const { check(pt_write_image(ctx_, path.c_str())); }

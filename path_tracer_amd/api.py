@@ -30,7 +30,7 @@ DEFAULT_SEED = 0x5EED5EED
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
-    "pt_read_accumulation", "pt_render_samples", "pt_active_pixels", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
+    "pt_read_accumulation", "pt_read_frame", "pt_write_accumulation", "pt_render_samples", "pt_active_pixels", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_step_stats",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
@@ -117,6 +117,8 @@ def lib():
         L.pt_reset_accumulation.argtypes = [vp]
         L.pt_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.pt_read_accumulation.argtypes = [vp, vp]
+        L.pt_write_accumulation.argtypes = [vp, vp, vp, vp]
+        L.pt_read_frame.argtypes = [vp, vp, vp, vp]
         L.pt_render_samples.argtypes = [vp, u32, u32, vp]
         L.pt_local_rows.argtypes = [vp, C.POINTER(u32), vp, u32]
         L.pt_set_stream.argtypes = [vp, vp]
@@ -334,6 +336,20 @@ class Renderer:
         acc = np.zeros((rows, self.cfg.width, 4), np.float32)
         self._chk(self.L.pt_read_accumulation(self.ctx, _p(acc)))
         return acc
+
+    def read_frame(self):
+        """(accumulation, position, id history) as they lie on the device, e.g. after render_device()"""
+        rows = len(self.local_rows())
+        acc = np.zeros((rows, self.cfg.width, 4), np.float32); pos = np.zeros((rows, self.cfg.width, 4), np.float32); idb = np.zeros((rows, self.cfg.width), np.uint32)
+        self._chk(self.L.pt_read_frame(self.ctx, _p(acc), _p(pos), _p(idb)))
+        return acc, pos, idb
+
+    def write_accumulation(self, data, position=None, ident=None):
+        """Restore a frame's state (what render() returned) into this context: checkpoint / resume across contexts."""
+        data = np.ascontiguousarray(data, np.float32)
+        pos = None if position is None else np.ascontiguousarray(position, np.float32)
+        idb = None if ident is None else np.ascontiguousarray(ident, np.uint32)
+        self._chk(self.L.pt_write_accumulation(self.ctx, _p(data), None if pos is None else _p(pos), None if idb is None else _p(idb)))
 
     def accum_device_ptr(self):
         p = C.c_void_p()

@@ -1216,6 +1216,40 @@ int pt_read_accumulation(pt_ctx* c, float* data)
     return PT_OK;
 }
 
+// the frame's whole state as it lies on the device (any pointer may be null): what pt_write_accumulation takes back
+int pt_read_frame(pt_ctx* c, float* data, float* position, uint32_t* id)
+{
+    if (!c) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    const size_t px = c->local_pixels;
+    if (data && px) HIPCHK(c, hipMemcpyAsync(data, c->d_accum.p, px * 16, hipMemcpyDeviceToHost, c->stream));
+    if (position && px) HIPCHK(c, hipMemcpyAsync(position, c->d_position.p, px * 16, hipMemcpyDeviceToHost, c->stream));
+    if (id && px) HIPCHK(c, hipMemcpyAsync(id, c->d_id.p, px * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// Restore what pt_render / pt_read_frame returned into this context, so that a render stopped in one process continues in
+// another: accumulation (sum of rgb, sample count), and optionally the last sample's first-hit position and the id history
+// (accumulate.wgsl:20-23, main.rs:204-206).  Local pixels, row-major, like every other framebuffer of the API.
+int pt_write_accumulation(pt_ctx* c, const float* data, const float* position, const uint32_t* id)
+{
+    if (!c || !data) return PT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int r;
+    if ((r = ensure_device(c))) return r;
+    if ((r = ensure_frame(c))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the frame buffers may still be written by a render in flight
+    HIPCHK(c, hipMemcpyAsync(c->d_accum.p, data, (size_t)c->local_pixels * 16, hipMemcpyHostToDevice, c->stream));
+    if (position) HIPCHK(c, hipMemcpyAsync(c->d_position.p, position, (size_t)c->local_pixels * 16, hipMemcpyHostToDevice, c->stream));
+    if (id) HIPCHK(c, hipMemcpyAsync(c->d_id.p, id, (size_t)c->local_pixels * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 int pt_local_rows(pt_ctx* c, uint32_t* n_rows, uint32_t* rows, uint32_t cap)
 {
     if (!c || !n_rows) return PT_ERR_ARG;

@@ -1641,7 +1641,7 @@ struct ClosestKArgs
 typedef const __attribute__((address_space(4))) ClosestKArgs* ClosestKArgsPtr;
 // the kernel's single argument as it lies in the kernel-argument segment; the empty asm keeps the compiler from hoisting the loads
 // made through the pointer out of the section that makes them
-__device__ __forceinline__ ClosestKArgsPtr cold_args()
+[[maybe_unused]] __device__ __forceinline__ ClosestKArgsPtr cold_args()
 {
     ClosestKArgsPtr p = (ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));

@@ -223,6 +223,33 @@ def test_batching_resume_and_sharding_do_not_change_the_image(api, oracle_mod):
     assert_bit_equal(ref[0], o.render(48, 30, 6, max_bounces=5)[0], "vs oracle")
 
 
+def test_checkpoint_restores_into_a_fresh_context(api, oracle_mod):
+    """SURVEY 5 checkpoint / resume: context A renders samples [0, 2) and is read back; a NEW context gets that state through
+    pt_write_accumulation and renders sample 2: accumulation, position and the id history (which still holds sample 1) equal the
+    oracle's samples [0, 3) bit for bit."""
+    from path_tracer_amd import scenes
+    sc = scenes.cornell_mixed(40, 26)
+    a = api.Renderer(sc, 40, 26, max_bounces=6)
+    acc, pos, idb = a.render(0, 2)
+    a.close()
+    b = api.Renderer(sc, 40, 26, max_bounces=6)
+    b.write_accumulation(acc, pos, idb)
+    b.render_device(2, 1)                      # (render() would upload its own id buffer: the restored one must do)
+    got = b.read_frame()
+    o = oracle_mod.Oracle(sc)
+    oa, op, oi, _ = o.render(40, 26, 2, max_bounces=6)
+    oa, op, oi, _ = o.render(40, 26, 1, first_sample=2, max_bounces=6, accum=oa, ident=oi)
+    assert_bit_equal(got[0], oa, "restored accumulation + sample 2")
+    assert_bit_equal(got[1], op, "position of sample 2")
+    assert np.array_equal(got[2], oi), "id history across the restore"
+    assert (got[0][..., 3] == 3).all()
+    # only the accumulation restored: the frame still continues (id history then starts from zero)
+    c = api.Renderer(sc, 40, 26, max_bounces=6)
+    c.write_accumulation(acc)
+    c.render_device(2, 1)
+    assert_bit_equal(c.read_frame()[0], oa, "accumulation alone")
+
+
 def test_empty_and_edge_inputs(api, cornell64):
     r = api.Renderer(cornell64, 64, 64)
     z = np.zeros((0, 3), np.float32)

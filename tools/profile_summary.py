@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel-trace stats + separate --pmc passes) into profiles/<tag>_summary.md and
-profiles/<tag>_traffic.json.  Usage: tools/profile_summary.py <gpurun_out/prof dir> <tag>"""
+"""Condense rocprofv3 CSV output of tools/profile.sh (kernel-trace stats + separate --pmc passes of bench.py) into
+profiles/<tag>_summary.md and profiles/<tag>_traffic.json (what bench.py's `roofline.traffic` / `roofline_shade` read).
+Usage: tools/profile_summary.py <gpurun_out/prof_<tag> dir> <tag>"""
+import glob
 import json
 import os
 import re
@@ -15,42 +17,72 @@ def short(n):
     return re.sub(r"\(.*", "", n)
 
 
+def find(src, sub, name):
+    f = glob.glob(os.path.join(src, sub, "**", name), recursive=True)
+    return f[0] if f else None
+
+
+def bench_line(path):
+    out = None
+    if os.path.exists(path):
+        for ln in open(path):
+            if ln.startswith("{"):
+                out = json.loads(ln)
+    return out
+
+
 def main(src, tag):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
+    args = open(os.path.join(src, "args.txt")).read().strip() if os.path.exists(os.path.join(src, "args.txt")) else ""
     lines = [f"# rocprofv3 summary `{tag}` (MI355X, gfx950)", ""]
-    ks = pd.read_csv(os.path.join(src, "kt", "r1_kernel_stats.csv"))
+    kt_bench = bench_line(os.path.join(src, "kt.log"))
+    if kt_bench:
+        lines += [f"Workload: {kt_bench['config']['workload']} — {kt_bench['ms_per_step']:.2f} ms per step under the kernel trace, "
+                  f"{kt_bench['value'] / 1e3:.2f} Gray/s traversed ({kt_bench['config']['cast_Mray_per_s'] / 1e3:.2f} Gray/s at the reference's call sites).", ""]
+    ksf = find(src, "kt", "*kernel_stats.csv")
+    ks = pd.read_csv(ksf)
     ks["kernel"] = ks["Name"].map(short)
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline`", "",
+    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py {args} --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-ms` (two steps)", "",
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for _, r in ks.iterrows():
         lines.append(f"| {r['kernel']} | {r['Calls']} | {r['TotalDurationNs'] / 1e6:.2f} | {r['AverageNs'] / 1e3:.1f} | {r['Percentage']:.2f} |")
     lines += ["", "`k_closest<.., 1, ..>` (the BSDF-sampled NEE rays, about 1 % of them since the shading pass culls the rest) is launched on a side stream "
               "beside `k_any`: its duration overlaps `k_any`'s and mostly measures waiting for wave slots, so the column sums exceed the wall time."]
+    kt_ms = {r["kernel"]: r["TotalDurationNs"] / 1e6 for _, r in ks.iterrows()}
+    kt_steps = 2.0
     traffic = {}
     frames = []
+    pmc_bench = None
     for d in sorted(os.listdir(src)):
-        f = os.path.join(src, d, "r1_counter_collection.csv")
-        if d.startswith("pmc") and os.path.exists(f):
+        f = find(src, d, "*counter_collection.csv") if d.startswith("pmc") and os.path.isdir(os.path.join(src, d)) else None
+        if f:
             frames.append(pd.read_csv(f))
+        if d.startswith("pmc") and d.endswith(".log"):
+            pmc_bench = bench_line(os.path.join(src, d)) or pmc_bench
+    g = None
     if frames:
         pm = pd.concat(frames)
         pm["kernel"] = pm["Kernel_Name"].map(short)
         g = pm.groupby(["kernel", "Counter_Name"])["Counter_Value"].sum().unstack()
         n = pm.groupby(["kernel", "Counter_Name"])["Dispatch_Id"].nunique().unstack()
-        lines += ["", "## PMC passes (`--pmc`, one pass per counter group; bench.py --steps 1 --warmup 0 --spp 43)", "",
+        spp_p = pmc_bench["config"]["workload"].split(" spp")[0].split(", ")[-1] if pmc_bench else "?"
+        lines += ["", f"## PMC passes (`--pmc`, one pass per counter group; bench.py {args} --steps 1 --warmup 0, {spp_p} spp)", "",
                   "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                   "(MI355X_MICROARCH.md §HBM), so read bytes below = 2 x FETCH_SIZE x 1024.", ""]
         cols = [c for c in ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
-                            "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"] if c in g.columns]
+                            "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
+                            "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"] if c in g.columns]
         lines += ["| kernel | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
         for k, r in g.iterrows():
             lines.append(f"| {k} | " + " | ".join(f"{r[c]:.4g}" if pd.notna(r[c]) else "" for c in cols) + " |")
         if "SQ_ACTIVE_INST_VALU" in g.columns and "SQ_WAVE_CYCLES" in g.columns:
-            lines += ["", "| kernel | VALU-active share of wave lifetime | VALU wave-instr per wave |", "|---|---|---|"]
+            lines += ["", "| kernel | VALU-active share of wave lifetime | lanes per VALU instruction | VALU wave-instr per wave | L2 hit rate |", "|---|---|---|---|---|"]
             for k, r in g.iterrows():
                 if pd.notna(r.get("SQ_WAVE_CYCLES")) and r["SQ_WAVE_CYCLES"] > 0:
-                    lines.append(f"| {k} | {r['SQ_ACTIVE_INST_VALU'] / r['SQ_WAVE_CYCLES']:.3f} | {r['SQ_INSTS_VALU'] / max(r['SQ_WAVES'], 1):.0f} |")
+                    l2 = f"{r['TCC_HIT_sum'] / max(r['TCC_HIT_sum'] + r['TCC_MISS_sum'], 1):.2f}" if "TCC_HIT_sum" in g.columns and pd.notna(r.get("TCC_HIT_sum")) else ""
+                    lines.append(f"| {k} | {r['SQ_ACTIVE_INST_VALU'] / r['SQ_WAVE_CYCLES']:.3f} | {r['SQ_THREAD_CYCLES_VALU'] / max(r['SQ_ACTIVE_INST_VALU'], 1):.1f} | "
+                                 f"{r['SQ_INSTS_VALU'] / max(r['SQ_WAVES'], 1):.0f} | {l2} |")
         for k, r in g.iterrows():
             if "FETCH_SIZE" in g.columns and "WRITE_SIZE" in g.columns and pd.notna(r.get("FETCH_SIZE")) and pd.notna(r.get("WRITE_SIZE")):
                 launches = int(n.loc[k, "FETCH_SIZE"])
@@ -59,29 +91,40 @@ def main(src, tag):
                 traffic[k]["hbm_bytes_per_launch"] = traffic[k]["read_bytes_per_launch"] + traffic[k]["write_bytes_per_launch"]
     # the dominant kernel is k_closest in its two world modes (PRIMARY = bounce 0, WORLD = later bounces): bytes per traced ray
     try:
-        bench = None
-        for name in sorted(os.listdir(src)):
-            if name.startswith("pmc") and name.endswith(".log"):
-                for ln in open(os.path.join(src, name)):
-                    if ln.startswith("{"):
-                        bench = json.loads(ln)
-        rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]  # rays that reached the kernel in the profiled (timed) step
-        keys = [k for k in traffic if re.match(r"k_closest<\w+, [03](, \w+)?>$", k)]
+        rays = pmc_bench["roofline"]["rays_per_launch"] * pmc_bench["roofline"]["launches"]  # rays that reached the kernel in the profiled (timed) step
+        spp_p = int(pmc_bench["config"]["workload"].split(" spp")[0].split(", ")[-1])
+        keys = [k for k in traffic if re.match(r"k_closest\d?<\w+, [03](, \w+)*>$", k)]
         tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
-        va = sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) / sum(g.loc[k, "SQ_WAVE_CYCLES"] for k in keys) if "SQ_WAVE_CYCLES" in g.columns else None
-        ln = sum(g.loc[k, "SQ_THREAD_CYCLES_VALU"] for k in keys) / sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) if "SQ_THREAD_CYCLES_VALU" in g.columns else None
-        traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays, "spp": bench["config"]["workload"].split(" spp")[0].split(", ")[-1],
-                                      "valu_active_frac": va, "lanes_per_valu_instr": ln,
-                                      "note": "PMC passes at batch 43 spp; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read; valu_active_frac = "
-                                              "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's lifetime it issues VALU; x resident waves per SIMD = VALU busy), "
+        va = sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) / sum(g.loc[k, "SQ_WAVE_CYCLES"] for k in keys)
+        ln = sum(g.loc[k, "SQ_THREAD_CYCLES_VALU"] for k in keys) / sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys)
+        traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays, "spp": spp_p,
+                                      "valu_active_frac": va, "lanes_per_valu_instr": ln, "waves_per_simd": 4,
+                                      "algorithmic_bytes_per_ray": pmc_bench["roofline"].get("algorithmic_bytes_per_ray"),
+                                      "note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read; valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a "
+                                              "wave's lifetime it issues VALU; x waves_per_simd = VALU busy; 4 waves per SIMD are resident: 104-128 of 512 VGPRs each), "
                                               "lanes_per_valu_instr = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
-        if va is not None: lines += ["", f"k_closest PRIMARY+WORLD: VALU-active share of wave lifetime {va:.3f}; lanes active per VALU instruction {ln if ln is None else round(ln, 1)} of 64."]
-        lines += ["", f"Dominant kernel (k_closest, modes PRIMARY+WORLD): {tot / 1e9:.2f} GB of HBM traffic for {rays / 1e6:.1f} M rays = "
-                  f"**{tot / rays:.1f} B/ray** (algorithmic: 48 B/ray)."]
+        lines += ["", f"k_closest PRIMARY+WORLD: VALU-active share of wave lifetime {va:.3f} (x 4 resident waves per SIMD = {4 * va:.2f} VALU busy); lanes active per VALU instruction {ln:.1f} of 64 "
+                  f"(effective VALU use {4 * va * ln / 64:.2f}).",
+                  "", f"Dominant kernel (k_closest, modes PRIMARY+WORLD): {tot / 1e9:.2f} GB of HBM traffic for {rays / 1e6:.1f} M rays = **{tot / rays:.1f} B/ray** by the counters."]
+        # the memory-bound kernel: all shading launches of the profiled step
+        sk = [k for k in traffic if k.startswith("k_shade_surface")]
+        sb = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in sk)
+        s_ms = sum(v for k, v in kt_ms.items() if k.startswith("k_shade_surface")) / kt_steps
+        spp_kt = int(kt_bench["config"]["workload"].split(" spp")[0].split(", ")[-1]) if kt_bench else spp_p
+        traffic["k_shade_surface"] = {"kernels": sk, "hbm_bytes": sb, "spp": spp_p, "hbm_bytes_per_spp": sb / spp_p,
+                                      "kernel_trace_ms_per_step": s_ms, "kernel_trace_spp": spp_kt,
+                                      "GBps": (sb / spp_p * spp_kt) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None}
+        if s_ms > 0:
+            gbps = traffic["k_shade_surface"]["GBps"]
+            lines += ["", f"Shading pass (k_shade_surface, all launches): {sb / 1e9:.2f} GB per {spp_p}-spp step by the counters = {sb / spp_p / 1e6:.1f} MB per spp; "
+                      f"{s_ms:.2f} ms per {spp_kt}-spp step in the kernel trace -> **{gbps:.0f} GB/s = {gbps / 8000:.2f} of the 8 TB/s peak**."]
     except Exception as e:  # noqa: BLE001
         lines += ["", f"(bytes per ray not derived: {e})"]
     open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
+    if ksf:
+        import shutil
+        shutil.copy(ksf, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
     print("\n".join(lines))
 
 

@@ -214,8 +214,11 @@ def main():
         if lds_scene:
             alg_per_ray, alg_src = float(BYTES_PER_CLOSEST_RAY), "48 B per closest-hit ray (32 in + 16 out; the BVH never leaves the chip)"
         elif cb is not None:
-            alg_per_ray = BYTES_PER_CLOSEST_RAY + 32.0 * cb["nodes_visited_per_closest_ray"] + 48.0 * cb["triangles_tested_per_closest_ray"]
-            alg_src = "48 + 32 per node visited + 48 per triangle tested, nodes / triangles per ray from the oracle's counters 6, 7 on this run's cpu_baseline sample"
+            # the oracle's averages are per CAST; the casts answered by the root-box projection visit no node, so per ray that enters the kernel:
+            per_cast = 32.0 * cb["nodes_visited_per_closest_ray"] + 48.0 * cb["triangles_tested_per_closest_ray"]
+            alg_per_ray = BYTES_PER_CLOSEST_RAY + per_cast * st.rays_closest / max(traced_closest_local, 1)
+            alg_src = ("48 + (32 per node visited + 48 per triangle tested) per ray that enters the kernel; nodes / triangles per cast from the oracle's counters 6, 7 on this "
+                       "run's cpu_baseline sample, x casts / traversed rays")
         elif kc.get("algorithmic_bytes_per_ray"):
             alg_per_ray, alg_src = float(kc["algorithmic_bytes_per_ray"]), f"profiles/{pname} (oracle counters 6, 7 at profiling time)"
         else:

@@ -68,10 +68,12 @@ typedef struct pt_config
     uint32_t flags;           /* PT_FLAG_* */
     /* tuning / test knobs; 0 => the library's default */
     uint32_t stack_lds_levels; /* traversal-stack levels kept in LDS (default 14); deeper levels of deep BVHs spill to HBM */
-    uint32_t queue_slack;      /* extra ray-queue slots beyond one per path, in 1/1024ths of the path count (default 128 = 1/8, plus a
-                                  constant); producers reserve queue regions and return unused tails as holes.  A queue that would
-                                  overflow is never written past its end: the render returns PT_ERR_LIMIT.  Tests set bit 31 to see that:
-                                  the low 16 bits are then the WHOLE capacity in 1/1024ths of the path count. */
+    uint32_t queue_slack;      /* 0 (the default): shade / terminal queues hold one slot per path + 1/8 + 4 M slots (producers reserve queue
+                                  regions and return unused tails as holes).  Non-zero: the slack is EXACTLY this many 1/1024ths of the path
+                                  count and the 4 M-slot constant is dropped — so 128 is NOT the default and can be too little for small
+                                  batches.  A queue that would overflow is never written past its end: the render returns PT_ERR_LIMIT, and
+                                  a render that fails leaves the accumulation RESET (it may have received incomplete samples).  Tests set
+                                  bit 31 to see that: the low 16 bits are then the WHOLE capacity in 1/1024ths of the path count. */
     uint32_t pipelines;        /* wavefront batches in flight on separate HIP streams (default 2; 1 = strictly one after another) */
     uint32_t reserved;
 } pt_config;
@@ -132,7 +134,8 @@ int pt_create_ray(pt_ctx* ctx, float s, float t, float o[3], float d[3]); /* hos
  *   data_rgba  : the accumulation buffer after this call (acc.rgb / acc.w is the displayed mean, shader.wgsl:63)
  *   position   : first-hit xyz + t of the LAST sample (main.rs:205)
  *   id         : (id << 16) | new_id applied once per sample (main.rs:206); in/out
- * Blocking. */
+ * Blocking.  On failure every launch already enqueued has been waited for and the accumulation buffer and id history are reset to zero
+ * (batches pipelined behind a failed one may have added incomplete samples). */
 int pt_render(pt_ctx* ctx, uint32_t first_sample, uint32_t n_samples, float* data_rgba, float* position_xyzt, uint32_t* id);
 /* The rectangle of pixels camera rays are generated for (host computation, no GPU): columns [rect[0], rect[0]+rect[1]) and LOCAL rows
  * [rect[2], rect[2]+rect[3]) of this rank.  Every camera ray of a pixel outside it misses the world TLAS's root box (returned in

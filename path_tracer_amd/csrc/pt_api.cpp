@@ -608,6 +608,7 @@ int harvest_batch(pt_ctx* c, int pipe)
 // One batch's launches, cut at the bounces so that the batches of several pipelines can be enqueued side by side (render_common):
 // batch_begin, batch_bounce(0..max_bounces), batch_end.  Everything is asynchronous on the pipeline's streams except the
 // every-fourth-bounce look at the counters that long bounce budgets use to stop early.
+enum : uint32_t { kEagerRows = 18u }; // bookkeeping rows cleared when a batch begins (bounces 0..16); deeper ones are cleared as the bounces are enqueued
 struct BatchRun
 {
     pt_ctx* c = nullptr;
@@ -617,7 +618,7 @@ struct BatchRun
     EnvView env{};
     TraceLaunch tl{}, tl_side{};
     hipStream_t s = nullptr;
-    uint32_t rows = 0, shade_blocks = 1, last_row = 0, count = 0;
+    uint32_t rows = 0, shade_blocks = 1, last_row = 0, count = 0, cleared_rows = 0;
     bool nee = false, side_busy = false, stopped = false, write_position = false, aux_with_samples = false;
     int nee_err = PT_OK;
     f4* samples_out = nullptr;
@@ -676,9 +677,13 @@ int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32
         br.env.w = c->env_w;
         br.env.h = c->env_h;
     }
-    HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)br.rows * sizeof(Counters), br.s));
-    HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)br.rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, br.s));
-    HIPCHK(c, hipMemsetAsync(wb.tails, 0, (size_t)br.rows * Q_COUNT * kTailWordsPerQueue * 4, br.s));
+    // per-bounce bookkeeping (64 B of counters + 24 KB of claim cursors + 40 KB of striped tails per row): the first kEagerRows rows are
+    // cleared here, the rows of deeper bounces one bounce ahead of their first use (batch_bounce) — the reference's default budget of
+    // 1024 bounces would otherwise cost 67 MB of memset and a 25 MB read-back per batch, also for an interactive 1-spp frame
+    br.cleared_rows = std::min<uint32_t>(br.rows, kEagerRows);
+    HIPCHK(c, hipMemsetAsync(wb.counters, 0, (size_t)br.cleared_rows * sizeof(Counters), br.s));
+    HIPCHK(c, hipMemsetAsync(wb.heads, 0, (size_t)br.cleared_rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, br.s));
+    HIPCHK(c, hipMemsetAsync(wb.tails, 0, (size_t)br.cleared_rows * Q_COUNT * kTailWordsPerQueue * 4, br.s));
 #if PT_WAVE_TIMES
     HIPCHK(c, hipMemsetAsync(wb.wave_times, 0, (size_t)br.rows * kWaveTimeSlots * 16, br.s));
     HIPCHK(c, hipMemsetAsync(wb.wave_times_any, 0, (size_t)br.rows * kWaveTimeSlots * 16, br.s));
@@ -729,6 +734,14 @@ int batch_bounce(BatchRun& br, uint32_t b)
     const pt_config& g = c->cfg;
     const WavefrontBuffers& wb = pp.wb;
     hipStream_t s = br.s;
+    // bounce b touches rows b and b + 1 (the shading pass appends to the next bounce's queues)
+    while (br.cleared_rows < std::min<uint32_t>(br.rows, b + 2u))
+    {
+        const uint32_t row = br.cleared_rows++;
+        HIPCHK(c, hipMemsetAsync(wb.counters + row, 0, sizeof(Counters), s));
+        HIPCHK(c, hipMemsetAsync(wb.heads + (size_t)row * HEADS_PER_ROW * kHeadWordsPerQueue, 0, (size_t)HEADS_PER_ROW * kHeadWordsPerQueue * 4, s));
+        HIPCHK(c, hipMemsetAsync(wb.tails + (size_t)row * Q_COUNT * kTailWordsPerQueue, 0, (size_t)Q_COUNT * kTailWordsPerQueue * 4, s));
+    }
     if (b > 0 && br.nee) batch_nee_launches(br, b - 1);
 #if !PT_JOIN_LATE
     batch_join_side(br);
@@ -778,10 +791,12 @@ int batch_end(BatchRun& br)
         launch_accumulate(s, rp, br.cam, wb, (f4*)c->d_accum.p, (f4*)c->d_position.p, (uint32_t*)c->d_id.p, br.write_position ? 1u : 0u, 1u);
     }
     HIPCHK(c, hipEventRecord(pp.ev_done, s));
-    HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)br.rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)br.rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
+    // only the rows the batch used come back (all of them were cleared: last_row + 1 <= cleared_rows)
+    const uint32_t used_rows = std::min<uint32_t>(br.rows, std::min<uint32_t>(br.last_row + 1u, br.cleared_rows));
+    HIPCHK(c, hipMemcpyAsync(pp.h_counters, wb.counters, (size_t)used_rows * sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(pp.h_heads, wb.heads, (size_t)used_rows * HEADS_PER_ROW * kHeadWordsPerQueue * 4, hipMemcpyDeviceToHost, s));
     pp.busy = true;
-    pp.busy_rows = br.rows;
+    pp.busy_rows = used_rows;
     pp.busy_paths = (uint64_t)rp.local_pixels * br.count;
     pp.busy_culled = (uint64_t)(rp.local_pixels - rp.act_pixels) * br.count;
     return PT_OK;
@@ -868,8 +883,14 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // pipelines this call does not use give their memory back
     for (int i = (int)n_pipes; i < pt_ctx::kMaxPipes; ++i)
         if (!c->pipe[i].busy && c->pipe[i].cap_paths) free_pipe_pool(c->pipe[i]);
+    // ... and a pipeline that kept a larger pool from an earlier request (a whole frame resident on pipeline 0, say) gives it back when
+    // the pipelines have to share the budget: its old pool plus the others' new ones could exceed what max_paths was computed from
+    const size_t need_paths = (size_t)batch * act_pixels;
+    if (n_pipes > 1)
+        for (uint32_t i = 0; i < n_pipes; ++i)
+            if (!c->pipe[i].busy && c->pipe[i].cap_paths > need_paths + need_paths / 4) free_pipe_pool(c->pipe[i]);
     for (uint32_t i = 0; i < n_pipes; ++i)
-        if ((r = ensure_wavefront(c, (int)i, (size_t)batch * act_pixels, c->cfg.max_bounces + 2))) return r;
+        if ((r = ensure_wavefront(c, (int)i, need_paths, c->cfg.max_bounces + 2))) return r;
     DevBuf d_samples;
     if (samples_out && (r = dev_alloc(c, d_samples, (size_t)batch * c->local_pixels * 16))) return r;
     const auto t0 = std::chrono::steady_clock::now();
@@ -927,8 +948,25 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // whatever the caller queues next on pipeline 0's stream comes after the last accumulation (harvest_batch has waited for every
     // pipeline, so this is already true for the host; the event keeps stream order explicit for callers that share the stream)
     if (!err && prev_done && n_pipes > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, prev_done, 0));
+    if (err)
+    {
+        // Launches of the failed batch (and of batches pipelined behind it) may still be running on the pipelines' streams, and on
+        // PT_ERR_LIMIT some batches have added incomplete samples to the frame: wait for everything, then drop the partial sums so that
+        // nothing stale can be read back as a result (pt_api.h: the accumulation is reset by a failed render).
+        for (int i = 0; i < pt_ctx::kMaxPipes; ++i)
+        {
+            (void)hipStreamSynchronize(c->pipe_stream(i));
+            if (c->pipe[i].side_stream) (void)hipStreamSynchronize(c->pipe[i].side_stream);
+            c->pipe[i].busy = false;
+        }
+        (void)hipGetLastError();
+        if (c->d_accum.p) (void)hipMemsetAsync(c->d_accum.p, 0, c->d_accum.bytes, c->stream);
+        if (c->d_id.p) (void)hipMemsetAsync(c->d_id.p, 0, c->d_id.bytes, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        dev_free(d_samples);
+        return err;
+    }
     dev_free(d_samples);
-    if (err) return err;
     c->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
@@ -1740,14 +1778,22 @@ int mfail(pt_multi* m, int code, const std::string& msg)
     m->err = msg;
     return code;
 }
+#define MHIPCHK(m, call)                                                                                      \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) return mfail((m), PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
 // Scene::new happened on rank 0's context: every other context gets a copy of the built host scene, camera and environment
 int multi_replicate(pt_multi* m)
 {
     pt_ctx* c0 = m->ctx[0];
+    std::lock_guard<std::mutex> lk0(c0->mu); // rank 0's scene must not change under the copies (pt_add_model / pt_build from another thread)
     if (m->replicated_version == c0->scene_version) return PT_OK;
     for (size_t i = 1; i < m->ctx.size(); ++i)
     {
         pt_ctx* c = m->ctx[i];
+        if (c == c0) continue;
         std::lock_guard<std::mutex> lk(c->mu);
         c->scene = c0->scene;
         c->scene_uploaded = false;
@@ -1842,7 +1888,7 @@ int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, floa
         std::lock_guard<std::mutex> lk(c->mu);
         if ((r = ensure_device(c)) || (r = ensure_frame(c))) return mfail(m, r, pt_last_error(c));
     }
-    HIPCHK(c0, hipSetDevice(c0->device));
+    MHIPCHK(m, hipSetDevice(c0->device));
     if ((r = dev_alloc(c0, m->d_parts, std::max<size_t>(part_px * n, 1) * 16)) || (r = dev_alloc(c0, m->d_full, std::max<size_t>(full_px, 1) * 16))) return mfail(m, r, pt_last_error(c0));
     m->used_rccl = false;
     if (m->distinct)
@@ -1869,21 +1915,21 @@ int pt_multi_render(pt_multi* m, uint32_t first_sample, uint32_t n_samples, floa
         m->used_rccl = true;
         for (size_t i = 1; i < n; ++i)
         {
-            HIPCHK(c0, hipSetDevice(m->ctx[i]->device));
-            HIPCHK(c0, hipStreamSynchronize(m->ctx[i]->stream));
+            MHIPCHK(m, hipSetDevice(m->ctx[i]->device));
+            MHIPCHK(m, hipStreamSynchronize(m->ctx[i]->stream));
         }
-        HIPCHK(c0, hipSetDevice(c0->device));
+        MHIPCHK(m, hipSetDevice(c0->device));
     }
     else
     {
         // contexts sharing a device (or RCCL ruled out): plain device-to-device copies on devices[0]'s stream
         for (size_t i = 0; i < n; ++i)
-            HIPCHK(c0, hipMemcpyAsync((uint8_t*)m->d_parts.p + i * part_px * 16, m->ctx[i]->d_accum.p, part_px * 16, hipMemcpyDeviceToDevice, c0->stream));
+            MHIPCHK(m, hipMemcpyAsync((uint8_t*)m->d_parts.p + i * part_px * 16, m->ctx[i]->d_accum.p, part_px * 16, hipMemcpyDeviceToDevice, c0->stream));
     }
     launch_post_deinterleave(c0->stream, g.width, g.height, (uint32_t)n, g.strip_rows, c0->pad_rows, (const f4*)m->d_parts.p, (f4*)m->d_full.p);
-    if (data_rgba) HIPCHK(c0, hipMemcpyAsync(data_rgba, m->d_full.p, full_px * 16, hipMemcpyDeviceToHost, c0->stream));
-    HIPCHK(c0, hipStreamSynchronize(c0->stream));
-    HIPCHK(c0, hipGetLastError());
+    if (data_rgba) MHIPCHK(m, hipMemcpyAsync(data_rgba, m->d_full.p, full_px * 16, hipMemcpyDeviceToHost, c0->stream));
+    MHIPCHK(m, hipStreamSynchronize(c0->stream));
+    MHIPCHK(m, hipGetLastError());
     return PT_OK;
 }
 
@@ -1893,7 +1939,7 @@ int pt_multi_write_image(pt_multi* m, const char* path)
     if (!m->d_full.p) return mfail(m, PT_ERR_STATE, "pt_multi_render has not been called");
     pt_ctx* c0 = m->ctx[0];
     const size_t px = (size_t)c0->cfg.width * c0->cfg.height;
-    HIPCHK(c0, hipSetDevice(c0->device));
+    MHIPCHK(m, hipSetDevice(c0->device));
     DevBuf d_rgb;
     int r = dev_alloc(c0, d_rgb, px * 3);
     if (r) return mfail(m, r, pt_last_error(c0));
@@ -1948,8 +1994,10 @@ int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint3
     const pt_ctx::Pipe& pp = c->pipe[c->last_pipe];
     if (!pp.h_counters || !pp.h_heads) return PT_ERR_STATE;
     const uint32_t rows = std::min(cap_rows, c->cfg.max_bounces + 2);
-    std::memcpy(rows16, pp.h_counters, (size_t)rows * sizeof(Counters));
-    for (uint32_t r = 0; r < rows; ++r)
+    const uint32_t have = std::min(rows, pp.busy_rows); // the batch read back only the rows it used; the others are zero
+    std::memset(rows16, 0, (size_t)rows * sizeof(Counters));
+    std::memcpy(rows16, pp.h_counters, (size_t)have * sizeof(Counters));
+    for (uint32_t r = 0; r < have; ++r)
     {
         uint32_t* o = rows16 + 16 * r;
         o[1] = o[3] = o[5] = 0;
@@ -2034,6 +2082,7 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
     {
         uint32_t* o = rows8 + 8 * r;
         std::memset(o, 0, 32);
+        if (r >= pp.busy_rows) continue; // not read back: the batch ended before this bounce
         const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue + HEADS_CLOSEST * kHeadWordsPerQueue;
         for (uint32_t g = 0; g < kQueueHeads; ++g)
             for (uint32_t k = 0; k < 8; ++k) o[k] += hrow[g * kHeadStrideWords + base + k];

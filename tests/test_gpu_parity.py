@@ -185,7 +185,7 @@ def test_config1_image_bit_exact(api, oracle_mod, cornell256):
 
 
 @pytest.mark.parametrize("kw", [dict(max_bounces=0), dict(max_bounces=1), dict(max_bounces=12), dict(enable_nee=False, max_bounces=6),
-                                dict(max_bounces=40), dict(n_sobol=2, max_bounces=3), dict(seed=12345, max_bounces=5)])
+                                dict(max_bounces=40), dict(max_bounces=1024), dict(n_sobol=2, max_bounces=3), dict(seed=12345, max_bounces=5)])
 def test_integrator_variants_bit_exact(api, oracle_mod, kw):
     from path_tracer_amd import scenes
     sc = scenes.cornell_mixed(40, 24)
@@ -194,7 +194,10 @@ def test_integrator_variants_bit_exact(api, oracle_mod, kw):
     okw = dict(kw)
     if "enable_nee" in okw:
         okw["enable_nee"] = int(okw["enable_nee"])
-    assert_bit_equal(r.render_samples(3, 3), o.render_samples(40, 24, 3, first_sample=3, **okw), str(kw))
+    want = o.render_samples(40, 24, 3, first_sample=3, **okw)
+    assert_bit_equal(r.render_samples(3, 3), want, str(kw))
+    # again in the same buffers: the per-bounce bookkeeping rows (cleared eagerly for the first 18 bounces, lazily beyond) must come up clean
+    assert_bit_equal(r.render_samples(3, 3), want, str(kw) + " (second render)")
 
 
 def test_batching_resume_and_sharding_do_not_change_the_image(api, oracle_mod):
@@ -221,6 +224,23 @@ def test_batching_resume_and_sharding_do_not_change_the_image(api, oracle_mod):
     assert_bit_equal(ref[0], full, "row-sharded render")
     o = oracle_mod.Oracle(sc)
     assert_bit_equal(ref[0], o.render(48, 30, 6, max_bounces=5)[0], "vs oracle")
+
+
+def test_pipelines_give_back_an_oversized_pool(api, oracle_mod):
+    """One resident batch on pipeline 0, then the same context asked for small batches on two pipelines: pipeline 0 must not keep its
+    large pool beside pipeline 1's new one (the budget is shared), and the image is still the oracle's."""
+    from path_tracer_amd import scenes
+    sc = scenes.cornell_box(64, 48)
+    r = api.Renderer(sc, 64, 48, max_bounces=5)
+    r.render(0, 16)
+    r.set_config(batch_spp=2, pipelines=2)
+    r.reset_accumulation()
+    got = r.render(0, 16)
+    fresh = api.Renderer(sc, 64, 48, max_bounces=5, batch_spp=2, pipelines=2)
+    fresh.render(0, 16)
+    assert r.stats().state_bytes == fresh.stats().state_bytes, (r.stats().state_bytes, fresh.stats().state_bytes)
+    o = oracle_mod.Oracle(sc)
+    assert_bit_equal(got[0], o.render(64, 48, 16, max_bounces=5)[0], "two small pipelines after one large batch")
 
 
 def test_checkpoint_restores_into_a_fresh_context(api, oracle_mod):
@@ -384,6 +404,7 @@ def test_full_queue_is_reported_not_overrun(api, oracle_mod):
     with pytest.raises(api.PtError) as e:
         tight.render(0, 16)
     assert e.value.code == -5 and "queue" in str(e.value)
+    assert not tight.read_accumulation().any(), "a failed render leaves the accumulation reset, not polluted with incomplete samples"
     assert_bit_equal(good.render_samples(0, 4), want, "neighbouring context after the overflow")
     tight.set_config(queue_slack=0)
     assert_bit_equal(tight.render_samples(0, 4), want, "same context with the default slack")

@@ -55,6 +55,8 @@ void launch_generate(hipStream_t s, const RenderParams& rp, const CameraView& ca
 // closest hit against the world TLAS for bounce `b`: reads rq[b&1], writes hits + shade queues of row b
 void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const CameraView& cam,
                         const EnvView& env);
+// the same for bounce b >= 1 together with the BSDF-sampled NEE launch of bounce b - 1, as ONE launch (a wave goes from queue to queue)
+void launch_trace_fused(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const EnvView& env);
 // NEE rays produced by the shading of bounce `b` (counter row b)
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // BSDF-sampled NEE rays: closest hit against the lights TLAS, then (same kernel, same lane) any-hit against the world

@@ -709,16 +709,34 @@ struct Stack8<true>
 __device__ uint4* g_any_times = nullptr; // where the shadow-ray launch in flight puts its per-wave time records (set in-stream by launch_trace_shadow)
 #endif
 // ------------------------------------------------------------------------------------------------ closest hit
-template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
-                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
-                                                  uint32_t* __restrict__ heads, const ClosestOut out)
+// a traversal kernel's single argument (one struct, so that it starts at offset 0 of the kernel-argument segment)
+struct ClosestKArgs
 {
-    extern __shared__ uint4 smem[];
+    SceneView sv;
+    const uint4* gblob;
+    const f4* ra;
+    const f4* rb;
+    const uint32_t* n_ptr;
+    uint32_t* heads;
+    uint32_t root, cap_in;
+    ClosestOut out;
+};
+typedef const __attribute__((address_space(4))) ClosestKArgs* ClosestKArgsPtr;
+typedef const __attribute__((address_space(4))) ClosestOut* ClosestOutPtr;
+// (the empty asm keeps the compiler from hoisting the loads made through the pointer out of the section that makes them)
+__device__ __forceinline__ ClosestOutPtr launder_args(ClosestOutPtr p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// (the kernel's body as a function of the staged scene: k_closest is one launch of it, k_trace_fused runs it before another)
+template <bool LDS_SCENE, int MODE, bool SPILL>
+__device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl, const uint32_t blob_words, uint4* smem, const uint32_t root, const f4* __restrict__ ra,
+                                             const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                             uint32_t* __restrict__ heads, const ClosestOutPtr outp)
+{
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
     if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
-    uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
     // per-lane stack of (node, t_enter), [level][thread] in LDS (conflict-free ds_read_b64 / ds_write_b64)
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv);
     const uint32_t prim_bits = sv.prim_bits;
@@ -749,7 +767,11 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     // the terminal queue's regions.  Without an environment map its entries are rare (paths that also cast a BSDF-sampled NEE ray): the
     // smallest region a wave can use keeps the queue's extent, and what k_shade_terminal reads, small (whole frame: its first launch
     // 185 -> ~30 us).  With one, every miss goes there: regions sized like any busy queue's.
-    const uint32_t rsize = out.finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
+    // The launch description is read through the kernel-argument segment where it is needed (the service section and the epilogue:
+    // s_load, scalar cache) instead of living in scalar registers across the traversal loop, which has none to spare (66 were spilled
+    // to vector lanes and read back with v_readlane in every service)
+    const uint32_t lights_world_root = MODE == CLOSEST_LIGHTS ? outp->world_root : 0u;
+    const uint32_t rsize = outp->finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
     const Stripes stripes = stripes_for(plan.n);
     uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -763,6 +785,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
         const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
         if (service)
         {
+            const ClosestOutPtr out = launder_args(outp);
             // ---- retire finished lanes
             const uint64_t pm = __ballot(pending);
             if (pm != 0ull)
@@ -773,27 +796,27 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                     if (MODE == CLOSEST_PRIMARY)
                     {
                         // a primary miss is a finished path: accumulated = 0 + 0.006 * 1 (integrator.rs:265), defaults of :156-157
-                        const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
+                        const bool missed = pending && bid == MISS_ID && out->finalize_miss != 0u;
                         // one byte per camera ray instead of a 16-byte radiance record for the (usually many) rays that leave at once:
                         // k_accumulate reads PRIMARY_MISS as radiance (0.006, 0.006, 0.006)
-                        if (pending) out.occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
+                        if (pending) out->occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
                         if (missed)
                         {
-                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
-                            if (ray_idx >= out.keep_pos_from)
+                            if (ray_idx >= out->keep_id_from) out->first_id[ray_idx - out->keep_id_from] = 255u;
+                            if (ray_idx >= out->keep_pos_from)
                             {
                                 const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
+                                out->first_pos[ray_idx - out->keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
                             }
                         }
                         else if (pending && bid == MISS_ID)
                         {
                             // environment map present: the terminal pass shades the miss; defaults of integrator.rs:156-157 still apply
-                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
-                            if (ray_idx >= out.keep_pos_from)
+                            if (ray_idx >= out->keep_id_from) out->first_id[ray_idx - out->keep_id_from] = 255u;
+                            if (ray_idx >= out->keep_pos_from)
                             {
                                 const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
+                                out->first_pos[ray_idx - out->keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
                             }
                         }
                         qm = __ballot(pending && !missed);
@@ -809,7 +832,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                         uint32_t mat_id = 0;
                         if (pending)
                         {
-                            if (bid == MISS_ID) ends = out.finalize_miss != 0u;
+                            if (bid == MISS_ID) ends = out->finalize_miss != 0u;
                             else
                             {
                                 const uint4 meta = bl.inst[7u * (bid >> prim_bits) + 6u];
@@ -819,7 +842,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                         }
                         if (ends)
                         {
-                            const DPathRec& rec = out.rec[pid];
+                            const DPathRec& rec = out->rec[pid];
                             const f4 acc4 = rec.acc;
                             const uint32_t flags = asu(acc4.w);
                             if (!(flags & FLAG_BSDF_CAST))
@@ -828,12 +851,12 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                                 if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
                                 const f3 pw = xyz(rec.pw);
                                 if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
-                                else if (!out.enable_nee || (flags & FLAG_LAST_DELTA))
+                                else if (!out->enable_nee || (flags & FLAG_LAST_DELTA))
                                 {
                                     const DMaterial& m = sv.materials[mat_id];
                                     acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
                                 }
-                                out.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f};
+                                out->radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f};
                                 pending = false;
                             }
                         }
@@ -849,26 +872,26 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
 #pragma unroll
                         for (uint32_t c = 0; c < Q_COUNT; ++c)
                         {
-                            if (!((out.class_mask >> c) & 1u)) continue;
+                            if (!((out->class_mask >> c) & 1u)) continue;
                             const uint64_t m = __ballot(cls == c);
                             if (m == 0ull) continue;
                             const Placement pl = c == Q_TERMINAL
-                                ? wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize, out.cap_term, out.overflow)
-                                : wave_reserve_striped(bin_region[c], out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), out.cap_shade, out.overflow);
+                                ? wave_reserve(bin_region[c], out->n_shade + c, (uint32_t)__popcll(m), rsize, out->cap_term, out->overflow)
+                                : wave_reserve_striped(bin_region[c], out->tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), out->cap_shade, out->overflow);
                             if (cls == c)
                             {
                                 const uint32_t pos = place(pl, mbcnt64(m));
                                 if (c == Q_TERMINAL)
                                 {
-                                    out.hits[ray_idx] = hit;
-                                    out.q_term[pos] = make_uint2(ray_idx, pid);
+                                    out->hits[ray_idx] = hit;
+                                    out->q_term[pos] = make_uint2(ray_idx, pid);
                                 }
                                 else
                                 {
-                                    f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride + pos;
+                                    f4* const qa = out->q_base + (size_t)(3u * ((out->q_class_slot >> (4u * c)) & 0xfu)) * out->q_stride + pos;
                                     nt_store(qa, f4{w.d.x, w.d.y, w.d.z, asf(pid)});
-                                    nt_store(qa + out.q_stride, hit);
-                                    if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)out.q_stride, f4{w.o.x, w.o.y, w.o.z, 0.0f});
+                                    nt_store(qa + out->q_stride, hit);
+                                    if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)out->q_stride, f4{w.o.x, w.o.y, w.o.z, 0.0f});
                                 }
                             }
                         }
@@ -878,13 +901,13 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                 {
                     if (pending)
                     {
-                        out.occl[pid] = (uint8_t)chain_code;
-                        if (chain_code == 0u) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
+                        out->occl[pid] = (uint8_t)chain_code;
+                        if (chain_code == 0u) out->hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)}; // only a visible light is ever read back
                     }
                 }
                 else
                 {
-                    if (pending) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
+                    if (pending) out->hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
                 }
                 pending = false;
             }
@@ -904,7 +927,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                 valid_rays += 1u;
                 if (MODE == CLOSEST_PRIMARY)
                 {
-                    w.o = out.eye;
+                    w.o = f3{out->eye.x, out->eye.y, out->eye.z};
                     t_max = asf(0x7f800000u);
                 }
                 else
@@ -1018,9 +1041,9 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
                     float te = 0.0f;
-                    const uint4 wr0 = bl.nodes[2u * out.world_root];
+                    const uint4 wr0 = bl.nodes[2u * lights_world_root];
                     // NaN t_max: every box test fails -> visible; so does a ray that misses the world's root box (tlas.rs:118-121)
-                    if (t_max == t_max && slab(wr0, bl.nodes[2u * out.world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
+                    if (t_max == t_max && slab(wr0, bl.nodes[2u * lights_world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
                     else { active = false; pending = true; chain_code = 0u; }
                     continue;
                 }
@@ -1124,26 +1147,27 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     }
     if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
     {
+        const ClosestOutPtr out = launder_args(outp);
         // hand back what is left of this wave's regions as holes (a hole is a path id of HOLE)
         const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
-        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) out.q_term[i] = make_uint2(HOLE, 0u);
+        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) out->q_term[i] = make_uint2(HOLE, 0u);
 #pragma unroll
         for (uint32_t c = 1; c < Q_COUNT; ++c)
         {
-            f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride;
+            f4* const qa = out->q_base + (size_t)(3u * ((out->q_class_slot >> (4u * c)) & 0xfu)) * out->q_stride;
             for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
         }
     }
 #if PT_WAVE_TIMES
     // one record per wave (100 MHz ticks, low 32 bits): start, first rays, queue found empty, end; the host reduces them
     // (pt_last_batch_step_stats in a PT_WAVE_TIMES build, tools/wave_times.py)
-    if (lane_id() == 0u && out.wave_times)
+    if (lane_id() == 0u && outp->wave_times)
     {
         const uint32_t tw_end = (uint32_t)wall_clock64();
         if (tw_drained == 0u) tw_drained = tw_end;
         if (tw_first == 0u) tw_first = tw_start;
         const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (wave < kWaveTimeSlots) out.wave_times[wave] = make_uint4(tw_start, tw_first, tw_drained, tw_end | 1u);
+        if (wave < kWaveTimeSlots) outp->wave_times[wave] = make_uint4(tw_start, tw_first, tw_drained, tw_end | 1u);
     }
 #endif
 #if PT_STEP_STATS
@@ -1164,6 +1188,17 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
     if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
     // any-hit casts of integrator.rs:103
     if (MODE == CLOSEST_LIGHTS) add_tally(heads, light_hits, HEAD_TALLY1);
+}
+template <bool LDS_SCENE, int MODE, bool SPILL>
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest(const ClosestKArgs a)
+{
+    extern __shared__ uint4 smem[];
+    // (workgroups the queue has no 64-ray chunk for leave before staging anything)
+    if (blockIdx.x >= fetch_plan(min(*a.n_ptr, a.cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER).blocks) return;
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
+    const ClosestOutPtr outp = &((ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr())->out;
+    closest_body<LDS_SCENE, MODE, SPILL>(a.sv, bl, blob_words, smem, a.root, a.ra, a.rb, a.n_ptr, a.cap_in, a.heads, outp);
 }
 
 // ------------------------------------------------------------------------------------------------ closest hit, leaves deferred
@@ -1627,18 +1662,6 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
 #ifndef PT_STREAM_STEPS
 #define PT_STREAM_STEPS 2   // wave-steps between two looks at the lanes' buffers
 #endif
-struct ClosestKArgs
-{
-    SceneView sv;
-    const uint4* gblob;
-    const f4* ra;
-    const f4* rb;
-    const uint32_t* n_ptr;
-    uint32_t* heads;
-    uint32_t root, cap_in;
-    ClosestOut out;
-};
-typedef const __attribute__((address_space(4))) ClosestKArgs* ClosestKArgsPtr;
 // the kernel's single argument as it lies in the kernel-argument segment; the empty asm keeps the compiler from hoisting the loads
 // made through the pointer out of the section that makes them
 [[maybe_unused]] __device__ __forceinline__ ClosestKArgsPtr cold_args()
@@ -2103,16 +2126,13 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 // tested when its parent is expanded (the instance's BLAS root right after the ray transform) and only nodes that were hit go
 // on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
 template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH_ANY : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
-                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
-                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
-                                              f4* __restrict__ radiance)
+__device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, const uint32_t blob_words, uint4* smem, const uint32_t root, const f4* __restrict__ ra,
+                                         const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                         uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
+                                         f4* __restrict__ radiance)
 {
-    extern __shared__ uint4 smem[];
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY);
     if (blockIdx.x >= plan.blocks) return;
-    uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv); // entries (node, entry distance of its box)
 
     bool active = false, ray_finite = false;
@@ -2280,6 +2300,57 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH_ANY : PT_WAV
         if (wave < kWaveTimeSlots) g_any_times[wave] = make_uint4(tw_start, tw_start, tw_drained, tw_end | 1u);
     }
 #endif
+}
+template <bool LDS_SCENE, int MODE, bool SPILL>
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH_ANY : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
+                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
+                                              f4* __restrict__ radiance)
+{
+    extern __shared__ uint4 smem[];
+    if (blockIdx.x >= fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY).blocks) return;
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
+    any_body<LDS_SCENE, MODE, SPILL>(sv, bl, blob_words, smem, root, ra, rb, n_ptr, cap_in, heads, occluded, radiance);
+}
+
+// One launch for two of the three traversals between two shading passes: the world closest-hit rays of bounce b, then the (few)
+// BSDF-sampled NEE rays the shading pass of bounce b - 1 cast.  Neither needs the other's results — the world launch finishes only
+// paths that cast no BSDF-sampled ray — so a wave that finds the first queue drained goes on to the second without waiting for
+// anybody: the NEE launch's own grid, its launch tail and the side stream's fork / join disappear from every bounce.
+// (The shadow rays of bounce b - 1 cannot join them: a path that ends at the world hit still owes its explicit-light estimate, and
+// k_closest<WORLD> reads what the shadow-ray launch left of it.  Tried all the same, with such paths sent through the terminal queue
+// instead: what the two saved launch tails return, the terminal pass takes.)
+struct FusedArgs
+{
+    const f4 *wa, *wb;          // world closest-hit rays of this bounce
+    const uint32_t* wn;
+    uint32_t* wheads;
+    const f4 *la, *lb;          // BSDF-sampled NEE rays of the bounce before
+    const uint32_t* ln;
+    uint32_t* lheads;
+    uint32_t world_root, lights_root, cap_in;
+};
+struct FusedKArgs
+{
+    SceneView sv;
+    const uint4* gblob;
+    FusedArgs fa;
+    ClosestOut wout, lout;
+};
+template <bool LDS_SCENE, bool SPILL>
+__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_trace_fused(const FusedKArgs a)
+{
+    extern __shared__ uint4 smem[];
+    const uint32_t cdiv = LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH;
+    const uint32_t need = max(fetch_plan(min(*a.fa.wn, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks, fetch_plan(min(*a.fa.ln, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks);
+    if (blockIdx.x >= need) return;
+    uint32_t blob_words;
+    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
+    typedef const __attribute__((address_space(4))) FusedKArgs* FusedKArgsPtr;
+    const FusedKArgsPtr k = (FusedKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    closest_body<LDS_SCENE, CLOSEST_WORLD, SPILL>(a.sv, bl, blob_words, smem, a.fa.world_root, a.fa.wa, a.fa.wb, a.fa.wn, a.fa.cap_in, a.fa.wheads, &k->wout);
+    closest_body<LDS_SCENE, CLOSEST_LIGHTS, SPILL>(a.sv, bl, blob_words, smem, a.fa.lights_root, a.fa.la, a.fa.lb, a.fa.ln, a.fa.cap_in, a.fa.lheads, &k->lout);
 }
 
 // ------------------------------------------------------------------------------------------------ path bookkeeping
@@ -2812,14 +2883,20 @@ __device__ __forceinline__ f3 finalise(f3 acc)
     return clamp_len_max(acc, 100.0f);
 }
 
-// accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206.  One thread per LOCAL pixel; a pixel
-// outside the active rectangle (RenderParams::act_*) never had a path: each of its samples is the miss result of integrator.rs:263-266
-// — radiance 0.006, id 255, position r.at(1e5) of that sample's camera ray (:156-157) — added sample by sample like any other.
+// accumulate.wgsl:20-23 applied once per sample, in sample order; id history shift main.rs:206.  A pixel outside the active rectangle
+// (RenderParams::act_*) never had a path: each of its samples is the miss result of integrator.rs:263-266 — radiance 0.006, id 255,
+// position r.at(1e5) of that sample's camera ray (:156-157) — added sample by sample like any other.
+// The sum must be taken in sample order (float addition does not associate), the loads and the per-sample finite check / clamp need not
+// wait for each other.  !FEW_PIXELS: one thread per LOCAL pixel, eight samples' loads in flight.  FEW_PIXELS (one rank's share of a
+// sharded frame: the active pixels fill ~250 workgroups, one wave per SIMD, and the kernel waits on memory latency): FOUR lanes per
+// pixel; lane q loads and finalises samples q, q + 4, ... and all four lanes then add the quad's values in sample order (DPP quad
+// broadcasts; the sums are redundant, the loads are not): four times the loads in flight.
 template <bool FEW_PIXELS>
 __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const CameraView cam, const PathState st, f4* accum, f4* position, uint32_t* id,
                                                      const uint32_t write_position, const uint32_t add_to_accum)
 {
-    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lp = FEW_PIXELS ? tid >> 2 : tid, q = FEW_PIXELS ? (tid & 3u) : 0u;
     if (lp >= rp.local_pixels) return;
     f4 a = accum[lp];
     uint32_t idv = id[lp];
@@ -2828,6 +2905,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
     {
         for (uint32_t s = 0; s < rp.batch_samples; ++s) a = f4{a.x + 0.006f, a.y + 0.006f, a.z + 0.006f, a.w + 1.0f};
         for (uint32_t s = rp.batch_samples >= 2u ? rp.batch_samples - 2u : 0u; s < rp.batch_samples; ++s) idv = (idv << 16) | 255u;
+        if (q != 0u) return;
         if (add_to_accum) accum[lp] = a;
         id[lp] = idv;
         if (write_position)
@@ -2839,35 +2917,68 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
         return;
     }
     const uint32_t k = (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0);
-    // eight samples' loads in flight at a time (the sum must be taken in sample order, the loads need not wait for each other).
-    // FEW_PIXELS (one rank's share of a sharded frame: too few threads to hide latency): sixteen, and the radiance load does not
-    // wait for the miss byte (a primary miss's record is stale memory inside the allocation; it is read and dropped)
-    constexpr uint32_t G = FEW_PIXELS ? 16 : 8;
-    for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += G)
+    if (FEW_PIXELS)
     {
-        uint32_t oc[G];
-        f4 rad[G];
-#pragma unroll
-        for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
-#pragma unroll
-        for (uint32_t j = 0; j < G; ++j)
+        constexpr uint32_t G = 4; // samples per lane and round: 16 per pixel
+        for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += 4u * G)
         {
-            if (FEW_PIXELS)
+            uint32_t oc[G];
+            f4 rad[G];
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j)
             {
-                const f4 r = (s0 + j) < rp.batch_samples ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{};
-                rad[j] = oc[j] != PRIMARY_MISS ? r : f4{0.006f, 0.006f, 0.006f, 0.0f};
+                const uint32_t s = s0 + 4u * j + q;
+                oc[j] = s < rp.batch_samples ? (uint32_t)st.occl[s * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
+                // (a primary miss's record is stale memory inside the allocation: read and dropped, so that the load need not wait for the byte)
+                rad[j] = s < rp.batch_samples ? st.radiance[s * rp.act_pixels + k] : f4{};
             }
-            else rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
-        }
+            f3 c[G];
 #pragma unroll
-        for (uint32_t j = 0; j < G; ++j)
+            for (uint32_t j = 0; j < G; ++j) c[j] = finalise(oc[j] != PRIMARY_MISS ? xyz(rad[j]) : f3{0.006f, 0.006f, 0.006f});
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j)
+            {
+#define PT_QUAD_ADD(SEL, QQ)                                                                                                           \
+                if (s0 + 4u * j + (QQ) < rp.batch_samples)                                                                          \
+                {                                                                                                                      \
+                    const float cx = asf(__builtin_amdgcn_mov_dpp(asu(c[j].x), SEL, 0xF, 0xF, true));                                 \
+                    const float cy = asf(__builtin_amdgcn_mov_dpp(asu(c[j].y), SEL, 0xF, 0xF, true));                                 \
+                    const float cz = asf(__builtin_amdgcn_mov_dpp(asu(c[j].z), SEL, 0xF, 0xF, true));                                 \
+                    a = f4{a.x + cx, a.y + cy, a.z + cz, a.w + 1.0f};                                                                  \
+                }
+                PT_QUAD_ADD(0x00, 0u) PT_QUAD_ADD(0x55, 1u) PT_QUAD_ADD(0xAA, 2u) PT_QUAD_ADD(0xFF, 3u)
+#undef PT_QUAD_ADD
+            }
+        }
+        if (q != 0u) return;
+        // (id << 16) | new once per sample: only the batch's last two samples are kept (RenderParams::keep_id_from)
+        for (uint32_t s = rp.batch_samples >= 2u ? rp.batch_samples - 2u : 0u; s < rp.batch_samples; ++s)
         {
-            if ((s0 + j) >= rp.batch_samples) break;
-            const uint32_t pid = (s0 + j) * rp.act_pixels + k;
-            const f3 c = finalise(xyz(rad[j]));
-            a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
-            // (id << 16) | new once per sample: only the last two samples survive in 32 bits
+            const uint32_t pid = s * rp.act_pixels + k;
             if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid - rp.keep_id_from];
+        }
+    }
+    else
+    {
+        constexpr uint32_t G = 8;
+        for (uint32_t s0 = 0; s0 < rp.batch_samples; s0 += G)
+        {
+            uint32_t oc[G];
+            f4 rad[G];
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j)
+            {
+                if ((s0 + j) >= rp.batch_samples) break;
+                const uint32_t pid = (s0 + j) * rp.act_pixels + k;
+                const f3 c = finalise(xyz(rad[j]));
+                a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
+                // (id << 16) | new once per sample: only the last two samples survive in 32 bits
+                if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid - rp.keep_id_from];
+            }
         }
     }
     if (add_to_accum) accum[lp] = a;
@@ -3034,10 +3145,13 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
     }
 #endif
     const size_t lds = trace_lds_bytes(tl);
-    if (tl.lds_scene && !spill) PT_LAUNCH((k_closest<true, MODE, false>));
-    else if (tl.lds_scene) PT_LAUNCH((k_closest<true, MODE, true>));
-    else if (!spill) PT_LAUNCH((k_closest<false, MODE, false>));
-    else PT_LAUNCH((k_closest<false, MODE, true>));
+    const ClosestKArgs ka{tl.scene, blob, rq.a, rq.b, n_ptr, heads, root, cap_in, out};
+#define PT_LAUNCH1(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
+    if (tl.lds_scene && !spill) PT_LAUNCH1((k_closest<true, MODE, false>));
+    else if (tl.lds_scene) PT_LAUNCH1((k_closest<true, MODE, true>));
+    else if (!spill) PT_LAUNCH1((k_closest<false, MODE, false>));
+    else PT_LAUNCH1((k_closest<false, MODE, true>));
+#undef PT_LAUNCH1
 #undef PT_LAUNCH
 }
 template <int MODE>
@@ -3098,6 +3212,48 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         out.finalize_miss = env.w == 0u ? 1u : 0u;
         launch_closest_impl<CLOSEST_WORLD>(s, tl, tl.scene.world_root, wb.rq[b & 1u], &row->n_closest, wb.cap_slots, row_heads(wb, b, HEADS_CLOSEST), out);
     }
+}
+// world closest hit of bounce b (b >= 1) + the BSDF-sampled NEE rays of bounce b - 1 in one launch (k_trace_fused)
+void launch_trace_fused(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b, const RenderParams& rp, const EnvView& env)
+{
+    Counters* row = wb.counters + b;
+    Counters* prev = wb.counters + (b - 1u);
+    ClosestOut wout{};
+    wout.hits = wb.hits;
+    wout.q_base = wb.q_shade_base;
+    wout.q_stride = wb.q_stride;
+    wout.q_class_slot = wb.q_class_slot;
+    wout.q_term = wb.q_term[b & 1u];
+    wout.n_shade = row->n_shade;
+    wout.tails = wb.tails + (size_t)b * Q_COUNT * kTailWordsPerQueue;
+    wout.wave_times = nullptr;
+    wout.cap_shade = wb.cap_slots_shade;
+    wout.cap_term = wb.cap_slots_term;
+    wout.class_mask = wb.class_mask | (1u << Q_TERMINAL);
+    wout.overflow = &row->overflow;
+    wout.rec = wb.st.rec;
+    wout.radiance = wb.st.radiance;
+    wout.enable_nee = rp.enable_nee;
+    wout.finalize_miss = env.w == 0u ? 1u : 0u;
+    ClosestOut lout{};
+    lout.hits = wb.lchain_hit;
+    lout.world_root = tl.scene.world_root;
+    lout.occl = wb.st.occl;
+    FusedArgs fa{};
+    fa.wa = wb.rq[b & 1u].a; fa.wb = wb.rq[b & 1u].b; fa.wn = &row->n_closest; fa.wheads = row_heads(wb, b, HEADS_CLOSEST);
+    fa.la = wb.rq_lchain[(b - 1u) & 1u].a; fa.lb = wb.rq_lchain[(b - 1u) & 1u].b; fa.ln = &prev->n_lchain; fa.lheads = row_heads(wb, b - 1u, HEADS_LCHAIN);
+    fa.world_root = tl.scene.world_root; fa.lights_root = tl.scene.lights_root; fa.cap_in = wb.cap_slots;
+    const size_t lds = trace_lds_bytes(tl);
+    const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
+    const dim3 block(tl.block_threads);
+    const uint4* blob = (const uint4*)tl.blob;
+    const FusedKArgs ka{tl.scene, blob, fa, wout, lout};
+#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
+    if (tl.lds_scene && !spill) PT_LAUNCH((k_trace_fused<true, false>));
+    else if (tl.lds_scene) PT_LAUNCH((k_trace_fused<true, true>));
+    else if (!spill) PT_LAUNCH((k_trace_fused<false, false>));
+    else PT_LAUNCH((k_trace_fused<false, true>));
+#undef PT_LAUNCH
 }
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)
 {
@@ -3178,7 +3334,7 @@ void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& 
                        uint32_t write_position, uint32_t add_to_accum)
 {
     const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
-    if (rp.local_pixels < (1u << 20)) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
+    if (rp.local_pixels < (1u << 20)) hipLaunchKernelGGL(k_accumulate<true>, dim3((rp.local_pixels * 4u + 255u) / 256u), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
     else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
 }
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)

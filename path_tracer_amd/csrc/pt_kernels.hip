@@ -285,6 +285,29 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, c
     return take;
 }
 
+// Which queue slot the k-th ray handed out is: slot k, unless PT_SHUFFLE_BITS deals the slots of every full block of 2^PT_SHUFFLE_BITS
+// rays in bit-reversed order (BVH in global memory only), so that the 64 lanes of a wave hold rays from all over the block instead of 64
+// neighbours.  An experiment, off by default.  Through the C-ABI hook (tools/sort_probe.py: rays leaving the camera rays' first hits on
+// the 82 k-triangle mesh in uniformly random directions) queue order took 480 us, sorted by direction octant x origin cell 467, 64- or
+// 1024-ray groups shuffled 440-445, every ray shuffled 340 us — mixing the rays INSIDE a wave paid, sorting them did not.  In the renderer
+// itself it does not: same-box A/B with 2^12 / 2^16 / 2^20-ray blocks on every launch: 82 k mesh 14.15 -> 14.4-14.5 ms, three spheres
+// 10.4 -> 10.8-11.1 ms (coherent camera rays and short shadow rays lose); on the world launches of bounces >= 1 only: 8.8 -> 8.8 ms of
+// closest-hit time on the 82 k mesh, 16.7-17.0 -> 16.7-16.9 ms on the 328 k mesh.  The bounce rays of a real frame are already mixed.
+#ifndef PT_SHUFFLE_BITS
+#define PT_SHUFFLE_BITS 0
+#endif
+#ifndef PT_SHUFFLE_WORLD_ONLY
+#define PT_SHUFFLE_WORLD_ONLY 1
+#endif
+template <bool LDS_SCENE, bool ENABLE = true>
+__device__ __forceinline__ uint32_t fetch_slot(uint32_t k, uint32_t n)
+{
+    if (LDS_SCENE || !ENABLE || PT_SHUFFLE_BITS == 0) return k;
+    const uint32_t block = k & ~((1u << PT_SHUFFLE_BITS) - 1u);
+    if (block + (1u << PT_SHUFFLE_BITS) > n) return k; // the queue's last, partial block stays in order
+    return block | (__brev(k) >> (32 - PT_SHUFFLE_BITS));
+}
+
 // exact count of what a wave processed, added to the cursor line of its home partition (64 addresses per queue instead of one)
 __device__ __forceinline__ void add_tally(uint32_t* heads, uint32_t per_lane, uint32_t word)
 {
@@ -919,7 +942,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
-                const uint32_t mine = first + rank;
+                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0 || MODE == CLOSEST_WORLD>(first + rank, plan.n);
                 const f4 b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
@@ -1406,7 +1429,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
-                const uint32_t mine = first + rank;
+                const uint32_t mine = fetch_slot<LDS_SCENE>(first + rank, plan.n);
                 const f4 b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
@@ -1887,7 +1910,7 @@ __global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_G
 #endif
             if (!nx_valid && rank < take)
             {
-                const uint32_t mine = first + rank;
+                const uint32_t mine = fetch_slot<LDS_SCENE>(first + rank, plan.n);
                 const f4 b = a.rb[mine];
                 nx_ridx = mine;
                 nx_pid = asu(b.w);
@@ -2187,7 +2210,7 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
-                const uint32_t mine = first + rank;
+                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0>(first + rank, plan.n);
                 const f4 a = ra[mine], b = rb[mine];
                 const uint32_t tag = asu(b.w);
                 if (tag != HOLE) {

@@ -305,7 +305,7 @@ __device__ __forceinline__ uint32_t fetch_slot(uint32_t k, uint32_t n)
     if (LDS_SCENE || !ENABLE || PT_SHUFFLE_BITS == 0) return k;
     const uint32_t block = k & ~((1u << PT_SHUFFLE_BITS) - 1u);
     if (block + (1u << PT_SHUFFLE_BITS) > n) return k; // the queue's last, partial block stays in order
-    return block | (__brev(k) >> (32 - PT_SHUFFLE_BITS));
+    return block | (__brev(k) >> ((32 - PT_SHUFFLE_BITS) & 31));
 }
 
 // exact count of what a wave processed, added to the cursor line of its home partition (64 addresses per queue instead of one)

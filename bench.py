@@ -132,10 +132,11 @@ def main():
             fb = ptdist.wrap_device_framebuffer(ptr, n_rows, width, dev)
             ptdist.gather_framebuffer(fb, height, width, rank, world, strip, dst=0)
 
-    if warmup == 0:
-        # the wavefront buffers are sized and allocated by the first render: do that outside the timed region with a request large enough
-        # to be cut into full-size batches (64 spp of a frame this large), not with a whole step
-        r.render_device(0, min(spp, 64))
+    if warmup == 0 and big:
+        # the wavefront buffers are sized and allocated by the first render (hipMalloc of ~240 GiB takes seconds): do that outside the timed
+        # region with a request large enough to be cut into the same full-size batches on two pipelines (256 spp of a frame this large), not
+        # with a whole step
+        r.render_device(0, min(spp, 256))
         torch.cuda.synchronize(dev)
     for _ in range(warmup):
         step()
@@ -167,7 +168,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_kernel_ms:
         # every kernel category timed, in a SECOND, untimed step (HIP events around every launch serialise the side stream and add
         # idle time, so they stay out of the timed region); long workloads time a 1/16 sample of the spp
-        r.set_config(flags=api.FLAG_TIMING_ALL)
+        r.set_config(flags=api.FLAG_TIMING_ALL, pipelines=1)   # one batch at a time: with two pipelines an event pair also spans the other pipeline's kernels
         r.reset_stats()
         spp_k = spp if not big else max(1, spp // 16)
         r.reset_accumulation()
@@ -177,7 +178,8 @@ def main():
         f = spp / spp_k
         kernel_ms = {"trace_closest": s2.ms_trace_closest * f, "trace_any": s2.ms_trace_any * f, "trace_light": s2.ms_trace_light * f, "shade": s2.ms_shade * f,
                      "generate": s2.ms_generate * f, "accumulate": s2.ms_accumulate * f,
-                     "source": "one extra untimed render with HIP events around every launch (PT_FLAG_TIMING_ALL); per step"
+                     "source": "one extra untimed render with HIP events around every launch (PT_FLAG_TIMING_ALL), batches one after another on one pipeline "
+                               "(the timed steps overlap the batches of two pipelines, so these can add up to more than ms_per_step); per step"
                                + ("" if spp_k == spp else f", measured on {spp_k} spp and scaled to {spp}")}
 
     if rank == 0:

@@ -896,11 +896,27 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
         batch = (uint32_t)std::max<size_t>(1, max_paths / n_pipes / act_pixels);
         n_batches = (n_samples + batch - 1) / batch;
     }
+    if (!c->cfg.batch_spp && n_batches > 1)
+    {
+        // pools that an earlier request left (a 64-spp warm-up before a 4096-spp render, say) are kept when they are nearly large enough:
+        // rounding n_samples / n_batches up differently must not cost a reallocation of hundreds of GB (seconds) inside a render
+        size_t cap_min = ~(size_t)0;
+        for (uint32_t i = 0; i < n_pipes; ++i) cap_min = std::min(cap_min, c->pipe[i].cap_paths);
+        const size_t want = (size_t)batch * act_pixels;
+        if (cap_min >= act_pixels && cap_min < want && cap_min * 4 >= want * 3)
+        {
+            batch = (uint32_t)(cap_min / act_pixels);
+            n_batches = (n_samples + batch - 1) / batch;
+        }
+    }
     batch = (n_samples + n_batches - 1) / n_batches;
     if ((uint64_t)batch * act_pixels >= (1ull << 29)) return fail(c, PT_ERR_ARG, "batch too large (path ids are 29-bit)");
     // pipelines this call does not use give their memory back
     for (int i = (int)n_pipes; i < pt_ctx::kMaxPipes; ++i)
         if (!c->pipe[i].busy && c->pipe[i].cap_paths) free_pipe_pool(c->pipe[i]);
+    if (std::getenv("PTMI_DEBUG_BATCH"))
+        std::fprintf(stderr, "[ptmi] render %u spp: max_paths %zu act_pixels %zu batch %u x %u on %u pipelines; pools before: %zu %zu paths\n", n_samples, max_paths, act_pixels, batch,
+                     n_batches, n_pipes, c->pipe[0].cap_paths, c->pipe[1].cap_paths);
     // ... and a pipeline that kept a larger pool from an earlier request (a whole frame resident on pipeline 0, say) gives it back when
     // the pipelines have to share the budget: its old pool plus the others' new ones could exceed what max_paths was computed from
     const size_t need_paths = (size_t)batch * act_pixels;

@@ -93,7 +93,8 @@ def main(src, tag):
     try:
         rays = pmc_bench["roofline"]["rays_per_launch"] * pmc_bench["roofline"]["launches"]  # rays that reached the kernel in the profiled (timed) step
         spp_p = int(pmc_bench["config"]["workload"].split(" spp")[0].split(", ")[-1])
-        keys = [k for k in traffic if re.match(r"k_closest\d?<\w+, [03](, \w+)*>$", k)]
+        # world closest-hit launches: k_closest<.., WORLD = 0 | PRIMARY = 3, ..> and k_trace_fused (bounces >= 1 of LDS scenes: world closest hit + the few BSDF-sampled NEE rays)
+        keys = [k for k in traffic if re.match(r"k_closest\d?<\w+, [03](, \w+)*>$", k) or k.startswith("k_trace_fused")]
         tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
         va = sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) / sum(g.loc[k, "SQ_WAVE_CYCLES"] for k in keys)
         ln = sum(g.loc[k, "SQ_THREAD_CYCLES_VALU"] for k in keys) / sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys)

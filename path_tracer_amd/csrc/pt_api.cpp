@@ -267,7 +267,10 @@ int upload_scene(pt_ctx* c)
 
     // launch geometry of the traversal kernels: BVH in LDS when it is small, per-lane stacks always in LDS
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
-    const size_t blob_lds = c->lds_scene ? blob.size() : 0;
+    // small LDS scenes: eight direction-octant copies of the node array, so that the box test needs no per-axis select (stage_scene)
+    const size_t oct_bytes = blob.size() + 7 * nb;
+    if (PT_OCT_NODES && c->lds_scene && oct_bytes <= PT_OCT_MAX_BYTES) sv.trav_flags |= TRAV_OCT_NODES;
+    const size_t blob_lds = c->lds_scene ? ((sv.trav_flags & TRAV_OCT_NODES) ? oct_bytes : blob.size()) : 0;
     uint32_t threads = 256;
 #ifndef PT_STACK_LDS_LEVELS
 #define PT_STACK_LDS_LEVELS 14

@@ -70,6 +70,9 @@ namespace {
 #ifndef PT_SORT_RETIRE
 #define PT_SORT_RETIRE 0
 #endif
+#if PT_TWO_PHASE != 0 && PT_OCT_NODES
+#error "k_closest2 / k_closest3 stage the plain BVH blob: build PT_TWO_PHASE variants with -DPT_OCT_NODES=0"
+#endif
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
@@ -572,6 +575,7 @@ struct Blob
     const uint4* tris;  // 3 words per triangle
     const uint4* inst;  // 7 words per instance
     const uint2* leaves; // big-leaf table {first, count} (NODE_TRIS_BIG)
+    uint32_t oct_stride; // octant copies of the node array (stage_scene<.., true>): 16-byte words from one copy to the next, else 0
 };
 // triangles of a leaf link
 __device__ __forceinline__ void leaf_range(const Blob& bl, uint32_t kind, uint32_t payload, uint32_t& first, uint32_t& count)
@@ -621,19 +625,51 @@ __device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, cons
     return r;
 }
 
-template <bool LDS_SCENE>
+// OCT (small LDS-resident BVHs, TRAV_OCT_NODES; an experiment, -DPT_OCT_NODES=1): the node array is written to LDS EIGHT times, copy k
+// holding every box as {the corner a ray of direction octant k reaches first | link, the opposite corner | aux} (k bit 0/1/2:
+// inv.x/y/z < 0).  The box test then needs no per-axis select of the nearer plane (slab_sorted: 11 VALU instructions instead of 17 — 12
+// of the ~50 a branch level costs), with the same operands in the same operations, so the same bits (all 82 GPU tests pass).  It is
+// SLOWER: Cornell 68.6 -> 76.1 ms per frame (closest-hit launches +17 %).  The 64 lanes of a wave expand at most 23 distinct child pairs
+// of this 46-node tree, so most of their four 16-byte LDS reads per level are the same address and are broadcast; with eight copies
+// the lanes of different octants read different addresses, a level becomes ~4 KB of LDS traffic per wave, and LDS bandwidth
+// (128 B per clock and CU, shared by 16 waves) binds before VALU issue does.  What the box test saves in instructions it pays in LDS time.
+template <bool LDS_SCENE, bool OCT = false>
 __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __restrict__ gblob, uint4* smem, uint32_t& words)
 {
     Blob b;
+    b.oct_stride = 0u;
     if (LDS_SCENE)
     {
-        words = sv.blob_bytes >> 4;
-        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) smem[i] = gblob[i];
+        const uint32_t plain = sv.blob_bytes >> 4, node_words = 2u * sv.n_nodes;
+        uint4* rest = smem;
+        if (OCT)
+        {
+            for (uint32_t i = threadIdx.x; i < sv.n_nodes; i += blockDim.x)
+            {
+                const uint4 w0 = gblob[2u * i], w1 = gblob[2u * i + 1u];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k)
+                {
+                    const bool nx = (k & 1u) != 0u, ny = (k & 2u) != 0u, nz = (k & 4u) != 0u;
+                    smem[k * node_words + 2u * i] = make_uint4(nx ? w1.x : w0.x, ny ? w1.y : w0.y, nz ? w1.z : w0.z, w0.w);
+                    smem[k * node_words + 2u * i + 1u] = make_uint4(nx ? w0.x : w1.x, ny ? w0.y : w1.y, nz ? w0.z : w1.z, w1.w);
+                }
+            }
+            rest = smem + 7u * node_words; // so that rest[i] is word i of the plain layout for i >= node_words
+            for (uint32_t i = node_words + threadIdx.x; i < plain; i += blockDim.x) rest[i] = gblob[i];
+            words = plain + 7u * node_words;
+            b.oct_stride = node_words;
+        }
+        else
+        {
+            words = plain;
+            for (uint32_t i = threadIdx.x; i < plain; i += blockDim.x) smem[i] = gblob[i];
+        }
         __syncthreads();
         b.nodes = smem;
-        b.tris = smem + 2u * sv.n_nodes;
-        b.inst = smem + 2u * sv.n_nodes + 3u * sv.n_tris;
-        b.leaves = reinterpret_cast<const uint2*>(smem + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
+        b.tris = rest + 2u * sv.n_nodes;
+        b.inst = rest + 2u * sv.n_nodes + 3u * sv.n_tris;
+        b.leaves = reinterpret_cast<const uint2*>(rest + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
     }
     else
     {
@@ -644,6 +680,25 @@ __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __
         b.leaves = reinterpret_cast<const uint2*>(gblob + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
     }
     return b;
+}
+// which copy a ray reads (the predicates of slab(): inv < 0 picks the max plane as the nearer one)
+__device__ __forceinline__ uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u); }
+// slab() on a box stored as (nearer corner, farther corner) for this ray's octant
+__device__ __forceinline__ bool slab_sorted(const uint4 wn, const uint4 wf, const f3 o, const f3 inv, const float t_max, float& t_enter)
+{
+    typedef float pair_t __attribute__((ext_vector_type(2)));
+    const pair_t px = (pair_t{asf(wn.x), asf(wf.x)} - pair_t{o.x, o.x}) * pair_t{inv.x, inv.x};
+    const pair_t py = (pair_t{asf(wn.y), asf(wf.y)} - pair_t{o.y, o.y}) * pair_t{inv.y, inv.y};
+    const pair_t pz = (pair_t{asf(wn.z), asf(wf.z)} - pair_t{o.z, o.z}) * pair_t{inv.z, inv.z};
+    const float ts = fmaxf(fmaxf(fmaxf(px.x, py.x), pz.x), PT_EPSILON);
+    const float tb = fminf(fminf(fminf(px.y, py.y), pz.y), t_max);
+    t_enter = ts;
+    return ts <= tb;
+}
+template <bool OCT>
+__device__ __forceinline__ bool slab_n(const uint4 w0, const uint4 w1, const f3 o, const f3 inv, const float t_max, float& t_enter)
+{
+    return OCT ? slab_sorted(w0, w1, o, inv, t_max, t_enter) : slab(w0, w1, o, inv, t_max, t_enter);
 }
 
 // CLOSEST_PRIMARY = CLOSEST_WORLD for bounce 0: every ray starts at the eye (only directions are stored, ray index == path id)
@@ -753,11 +808,12 @@ __device__ __forceinline__ ClosestOutPtr launder_args(ClosestOutPtr p)
     return p;
 }
 // (the kernel's body as a function of the staged scene: k_closest is one launch of it, k_trace_fused runs it before another)
-template <bool LDS_SCENE, int MODE, bool SPILL>
+template <int BVH, int MODE, bool SPILL>
 __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl, const uint32_t blob_words, uint4* smem, const uint32_t root, const f4* __restrict__ ra,
                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                              uint32_t* __restrict__ heads, const ClosestOutPtr outp)
 {
+    constexpr bool LDS_SCENE = BVH != 0, OCT = BVH == 2; // BVH: 0 in global memory, 1 in LDS, 2 in LDS with octant copies of the nodes (stage_scene)
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
     if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
     // per-lane stack of (node, t_enter), [level][thread] in LDS (conflict-free ds_read_b64 / ds_write_b64)
@@ -767,6 +823,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
     bool active = false, pending = false, ray_finite = false;
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
+    uint32_t nb_w = 0, nb_o = 0; // OCT: word offsets of the node copies of the world-space / object-space ray's direction octant
     float t_max = 0.0f, bt = 0.0f;
     float hud = 0.0f, hvd = 0.0f, hdet = 1.0f; // best hit's (u, v) numerators and determinant: divided once, when the ray retires (primitive.rs:158-160)
     uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0;
@@ -961,6 +1018,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 }
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
+                if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
                 ray_finite = finite3(w.o) && finite3(w.d);
                 bid = MISS_ID;
                 any_phase = false;
@@ -973,8 +1031,8 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 sp = stk.empty();
                 // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
                 float te;
-                const uint4 root0 = bl.nodes[2u * root];
-                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[nb_w + 2u * root];
+                const bool ok = (t_max == t_max) && slab_n<OCT>(root0, bl.nodes[nb_w + 2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
                     stk.put(sp, make_uint2(root0.w, 0u));    // entries are (link, t_enter); the root goes in with t_enter 0
@@ -1017,21 +1075,22 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 {
                     uint32_t blas_root;
                     ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
+                    if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                     in_blas = true;
                     blas_base = sp;
-                    const uint4 r0 = bl.nodes[2u * blas_root];
-                    if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                    const uint4 r0 = bl.nodes[nb_o + 2u * blas_root];
+                    if (!slab_n<OCT>(r0, bl.nodes[nb_o + 2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
                     link = r0.w;
                 }
                 const uint32_t kkind = link >> NODE_KIND_SHIFT, kpay = link & NODE_PAYLOAD_MASK;
                 if (kkind == NODE_BRANCH)
                 {
-                    const uint4* cp = bl.nodes + 2u * kpay;
+                    const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * kpay;
                     const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                     const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
                     float tl, tr;
-                    const bool hl = slab(l0, l1, so, sinv, t_max, tl);
-                    const bool hr = slab(r0, r1, so, sinv, t_max, tr);
+                    const bool hl = slab_n<OCT>(l0, l1, so, sinv, t_max, tl);
+                    const bool hr = slab_n<OCT>(r0, r1, so, sinv, t_max, tr);
                     if (hl) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }
                     if (hr) { stk.put(sp, make_uint2(r0.w, asu(tr))); sp = stk.up(sp); }
                 }
@@ -1064,9 +1123,9 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
                     float te = 0.0f;
-                    const uint4 wr0 = bl.nodes[2u * lights_world_root];
+                    const uint4 wr0 = bl.nodes[nb_w + 2u * lights_world_root];
                     // NaN t_max: every box test fails -> visible; so does a ray that misses the world's root box (tlas.rs:118-121)
-                    if (t_max == t_max && slab(wr0, bl.nodes[2u * lights_world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
+                    if (t_max == t_max && slab_n<OCT>(wr0, bl.nodes[nb_w + 2u * lights_world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
                     else { active = false; pending = true; chain_code = 0u; }
                     continue;
                 }
@@ -1089,6 +1148,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 uint32_t blas_root;
                 inst = link & NODE_PAYLOAD_MASK;
                 ob = to_object(bl, inst, w, ray_finite, blas_root);
+                if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                 in_blas = true;
                 blas_base = sp;
                 if (0.0f > t_max) continue;                  // the root's pop test  blas.rs:222-225
@@ -1106,12 +1166,12 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
 #pragma unroll 1
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS && kind == NODE_BRANCH; ++lvl)
             {
-                const uint4* cp = bl.nodes + 2u * payload; // the children are one contiguous 64-byte record pair
+                const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * payload; // the children are one contiguous 64-byte record pair
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
-                const bool hl = slab(l0, l1, o, inv, t_max, tl);
-                const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                const bool hl = slab_n<OCT>(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab_n<OCT>(r0, r1, o, inv, t_max, tr);
                 // both hit: the farther child goes underneath (ties: left underneath, right popped first); one hit: that child
                 const bool left_near = tl < tr;
                 const uint2 le = make_uint2(l0.w, asu(tl)), re = make_uint2(r0.w, asu(tr));
@@ -1212,16 +1272,17 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
     // any-hit casts of integrator.rs:103
     if (MODE == CLOSEST_LIGHTS) add_tally(heads, light_hits, HEAD_TALLY1);
 }
-template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest(const ClosestKArgs a)
+template <int BVH, int MODE, bool SPILL>
+__global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest(const ClosestKArgs a)
 {
+    constexpr bool LDS_SCENE = BVH != 0;
     extern __shared__ uint4 smem[];
     // (workgroups the queue has no 64-ray chunk for leave before staging anything)
     if (blockIdx.x >= fetch_plan(min(*a.n_ptr, a.cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER).blocks) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
+    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(a.sv, a.gblob, smem, blob_words);
     const ClosestOutPtr outp = &((ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr())->out;
-    closest_body<LDS_SCENE, MODE, SPILL>(a.sv, bl, blob_words, smem, a.root, a.ra, a.rb, a.n_ptr, a.cap_in, a.heads, outp);
+    closest_body<BVH, MODE, SPILL>(a.sv, bl, blob_words, smem, a.root, a.ra, a.rb, a.n_ptr, a.cap_in, a.heads, outp);
 }
 
 // ------------------------------------------------------------------------------------------------ closest hit, leaves deferred
@@ -2148,12 +2209,13 @@ enum { ANY_SHADOW = 0, ANY_HOOK = 2 };
 // box's own entry distance, so neither the visiting order nor the moment a box is tested can change it.  Here a node's box is
 // tested when its parent is expanded (the instance's BLAS root right after the ray transform) and only nodes that were hit go
 // on the stack, with their entry distance: a missed child costs a slab test instead of a full traversal step.
-template <bool LDS_SCENE, int MODE, bool SPILL>
+template <int BVH, int MODE, bool SPILL>
 __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, const uint32_t blob_words, uint4* smem, const uint32_t root, const f4* __restrict__ ra,
                                          const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                          uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                          f4* __restrict__ radiance)
 {
+    constexpr bool LDS_SCENE = BVH != 0, OCT = BVH == 2; // BVH: 0 in global memory, 1 in LDS, 2 in LDS with octant copies of the nodes (stage_scene)
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY);
     if (blockIdx.x >= plan.blocks) return;
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv); // entries (node, entry distance of its box)
@@ -2161,6 +2223,7 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
     bool active = false, ray_finite = false;
     uint32_t out_idx = 0, valid_rays = 0;
     LaneRay w{}, ob{};
+    uint32_t nb_w = 0, nb_o = 0; // OCT: word offsets of the node copies of the world-space / object-space ray's direction octant
     float t_max = 0.0f;
     uint32_t sp = stk.empty(), blas_base = 0;
     // ANY_SHADOW: `occluded` is PathState::rec: a blocked shadow ray erases the path's explicit-light candidate (integrator.rs:55-56,73)
@@ -2220,14 +2283,15 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 w.o = xyz(a);
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
+                if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
                 ray_finite = finite3(w.o) && finite3(w.d);
                 t_max = a.w;
                 in_blas = false;
                 sp = stk.empty();
                 // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
                 float te;
-                const uint4 root0 = bl.nodes[2u * root];
-                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[nb_w + 2u * root];
+                const bool ok = (t_max == t_max) && slab_n<OCT>(root0, bl.nodes[nb_w + 2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
                     stk.put(sp, make_uint2(root0.w, asu(te)));
@@ -2262,10 +2326,11 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
                 uint32_t blas_root;
                 ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
+                if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                 in_blas = true;
                 blas_base = sp;
-                const uint4 r0 = bl.nodes[2u * blas_root];
-                if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                const uint4 r0 = bl.nodes[nb_o + 2u * blas_root];
+                if (!slab_n<OCT>(r0, bl.nodes[nb_o + 2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
                 link = r0.w;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
@@ -2274,12 +2339,12 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
 #pragma unroll 1
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS_ANY && kind == NODE_BRANCH; ++lvl)
             {
-                const uint4* cp = bl.nodes + 2u * payload;
+                const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * payload;
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
-                const bool hl = slab(l0, l1, o, inv, t_max, tl);
-                const bool hr = slab(r0, r1, o, inv, t_max, tr);
+                const bool hl = slab_n<OCT>(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab_n<OCT>(r0, r1, o, inv, t_max, tr);
                 if (hl && hr) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
                 kind = NODE_INSTANCE; // nothing more in this step unless the next child says otherwise
                 if (hl || hr)
@@ -2324,17 +2389,18 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
     }
 #endif
 }
-template <bool LDS_SCENE, int MODE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH_ANY : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
+template <int BVH, int MODE, bool SPILL>
+__global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH_ANY : PT_WAVES_GLOBAL_BVH_ANY) k_any(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
                                               const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                               uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                               f4* __restrict__ radiance)
 {
+    constexpr bool LDS_SCENE = BVH != 0;
     extern __shared__ uint4 smem[];
     if (blockIdx.x >= fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY).blocks) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    any_body<LDS_SCENE, MODE, SPILL>(sv, bl, blob_words, smem, root, ra, rb, n_ptr, cap_in, heads, occluded, radiance);
+    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(sv, gblob, smem, blob_words);
+    any_body<BVH, MODE, SPILL>(sv, bl, blob_words, smem, root, ra, rb, n_ptr, cap_in, heads, occluded, radiance);
 }
 
 // One launch for two of the three traversals between two shading passes: the world closest-hit rays of bounce b, then the (few)
@@ -2361,19 +2427,20 @@ struct FusedKArgs
     FusedArgs fa;
     ClosestOut wout, lout;
 };
-template <bool LDS_SCENE, bool SPILL>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_trace_fused(const FusedKArgs a)
+template <int BVH, bool SPILL>
+__global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_trace_fused(const FusedKArgs a)
 {
+    constexpr bool LDS_SCENE = BVH != 0;
     extern __shared__ uint4 smem[];
     const uint32_t cdiv = LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH;
     const uint32_t need = max(fetch_plan(min(*a.fa.wn, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks, fetch_plan(min(*a.fa.ln, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks);
     if (blockIdx.x >= need) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
+    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(a.sv, a.gblob, smem, blob_words);
     typedef const __attribute__((address_space(4))) FusedKArgs* FusedKArgsPtr;
     const FusedKArgsPtr k = (FusedKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    closest_body<LDS_SCENE, CLOSEST_WORLD, SPILL>(a.sv, bl, blob_words, smem, a.fa.world_root, a.fa.wa, a.fa.wb, a.fa.wn, a.fa.cap_in, a.fa.wheads, &k->wout);
-    closest_body<LDS_SCENE, CLOSEST_LIGHTS, SPILL>(a.sv, bl, blob_words, smem, a.fa.lights_root, a.fa.la, a.fa.lb, a.fa.ln, a.fa.cap_in, a.fa.lheads, &k->lout);
+    closest_body<BVH, CLOSEST_WORLD, SPILL>(a.sv, bl, blob_words, smem, a.fa.world_root, a.fa.wa, a.fa.wb, a.fa.wn, a.fa.cap_in, a.fa.wheads, &k->wout);
+    closest_body<BVH, CLOSEST_LIGHTS, SPILL>(a.sv, bl, blob_words, smem, a.fa.lights_root, a.fa.la, a.fa.lb, a.fa.ln, a.fa.cap_in, a.fa.lheads, &k->lout);
 }
 
 // ------------------------------------------------------------------------------------------------ path bookkeeping
@@ -3075,9 +3142,11 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
     o[8] = (float)(rng.k - draws);
 }
 
+static bool oct_nodes(const TraceLaunch& tl) { return PT_OCT_NODES != 0 && tl.lds_scene && (tl.scene.trav_flags & TRAV_OCT_NODES) != 0u; }
 size_t trace_lds_bytes(const TraceLaunch& tl, bool with_cands = false)
 {
-    const size_t blob = tl.lds_scene ? tl.scene.blob_bytes : 0;
+    // (k_closest2 / k_closest3 stage the plain blob: with_cands)
+    const size_t blob = tl.lds_scene ? tl.scene.blob_bytes + (oct_nodes(tl) && !with_cands ? (size_t)7 * tl.scene.n_nodes * sizeof(DNode) : 0) : 0;
     return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8 + (with_cands ? (size_t)PT_CAND_SLOTS * tl.block_threads * 16 : 0);
 }
 
@@ -3170,10 +3239,11 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
     const size_t lds = trace_lds_bytes(tl);
     const ClosestKArgs ka{tl.scene, blob, rq.a, rq.b, n_ptr, heads, root, cap_in, out};
 #define PT_LAUNCH1(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
-    if (tl.lds_scene && !spill) PT_LAUNCH1((k_closest<true, MODE, false>));
-    else if (tl.lds_scene) PT_LAUNCH1((k_closest<true, MODE, true>));
-    else if (!spill) PT_LAUNCH1((k_closest<false, MODE, false>));
-    else PT_LAUNCH1((k_closest<false, MODE, true>));
+    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH1((k_closest<2, MODE, false>)); else PT_LAUNCH1((k_closest<2, MODE, true>)); } }
+    else if (tl.lds_scene && !spill) PT_LAUNCH1((k_closest<1, MODE, false>));
+    else if (tl.lds_scene) PT_LAUNCH1((k_closest<1, MODE, true>));
+    else if (!spill) PT_LAUNCH1((k_closest<0, MODE, false>));
+    else PT_LAUNCH1((k_closest<0, MODE, true>));
 #undef PT_LAUNCH1
 #undef PT_LAUNCH
 }
@@ -3186,10 +3256,11 @@ static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root,
     const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
 #define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, occluded, radiance)
-    if (tl.lds_scene && !spill) PT_LAUNCH((k_any<true, MODE, false>));
-    else if (tl.lds_scene) PT_LAUNCH((k_any<true, MODE, true>));
-    else if (!spill) PT_LAUNCH((k_any<false, MODE, false>));
-    else PT_LAUNCH((k_any<false, MODE, true>));
+    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH((k_any<2, MODE, false>)); else PT_LAUNCH((k_any<2, MODE, true>)); } }
+    else if (tl.lds_scene && !spill) PT_LAUNCH((k_any<1, MODE, false>));
+    else if (tl.lds_scene) PT_LAUNCH((k_any<1, MODE, true>));
+    else if (!spill) PT_LAUNCH((k_any<0, MODE, false>));
+    else PT_LAUNCH((k_any<0, MODE, true>));
 #undef PT_LAUNCH
 }
 
@@ -3272,10 +3343,11 @@ void launch_trace_fused(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     const uint4* blob = (const uint4*)tl.blob;
     const FusedKArgs ka{tl.scene, blob, fa, wout, lout};
 #define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
-    if (tl.lds_scene && !spill) PT_LAUNCH((k_trace_fused<true, false>));
-    else if (tl.lds_scene) PT_LAUNCH((k_trace_fused<true, true>));
-    else if (!spill) PT_LAUNCH((k_trace_fused<false, false>));
-    else PT_LAUNCH((k_trace_fused<false, true>));
+    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH((k_trace_fused<2, false>)); else PT_LAUNCH((k_trace_fused<2, true>)); } }
+    else if (tl.lds_scene && !spill) PT_LAUNCH((k_trace_fused<1, false>));
+    else if (tl.lds_scene) PT_LAUNCH((k_trace_fused<1, true>));
+    else if (!spill) PT_LAUNCH((k_trace_fused<0, false>));
+    else PT_LAUNCH((k_trace_fused<0, true>));
 #undef PT_LAUNCH
 }
 void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b)

@@ -131,8 +131,15 @@ struct SceneView
 enum : uint32_t
 {
     TRAV_ALL_IDENTITY = 1u, // every instance of both TLASes is the identity: one object-space image of a ray serves all of them
-    TRAV_NESTED_BOXES = 2u  // every child's box lies inside its parent's (bit for bit): box entry distances never decrease downwards
+    TRAV_NESTED_BOXES = 2u, // every child's box lies inside its parent's (bit for bit): box entry distances never decrease downwards
+    TRAV_OCT_NODES = 4u     // LDS-resident BVH small enough for eight direction-octant copies of its node array (set by the context, not the scene)
 };
+#ifndef PT_OCT_NODES
+#define PT_OCT_NODES 0      // 1: the experiment of stage_scene<.., OCT> (slower: LDS bandwidth; see there)
+#endif
+#ifndef PT_OCT_MAX_BYTES
+#define PT_OCT_MAX_BYTES (32u << 10) // most the eight copies + triangles + instances may take of a workgroup's LDS
+#endif
 // FIFO entries per lane of the closest-hit kernel with deferred leaves (k_closest2): 16 bytes each in LDS; power of two
 #ifndef PT_CAND_SLOTS
 #define PT_CAND_SLOTS 4

@@ -350,3 +350,21 @@ def test_python_host_loads_one_hip_runtime():
     )
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bench_configurations_name_real_scenes():
+    """bench.py --config: every configuration names a scene constructor that exists and takes its keyword arguments (built here for the
+    small ones; the meshes are generated and counted), and its own / default sample counts are consistent."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from path_tracer_amd import scenes
+    assert set(bench.CONFIGS) == {"cornell", "mesh82k", "mesh328k", "mixed", "spheres"}
+    for name, cfg in bench.CONFIGS.items():
+        fn, kw, w, h, spp_own, spp_default, depth, what = cfg
+        assert hasattr(scenes, fn), name
+        assert 1 <= spp_default <= spp_own and depth in (8, 16) and w * h >= 1920 * 1080
+    assert bench.make_scene(bench.CONFIGS["cornell"]).n_triangles() == 36
+    assert bench.make_scene(bench.CONFIGS["mesh82k"]).n_triangles() == 81932
+    assert bench.make_scene(bench.CONFIGS["mixed"]).n_triangles() == 36

@@ -111,11 +111,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # PT_BENCH_REHEARSAL=1: every rank on cuda:0 and gloo for the collectives (framebuffer staged through the host) — the N > 1 control
+    # flow of this file on a one-GPU box; RCCL refuses two ranks on one device.  Not a measurement.
+    rehearsal = world > 1 and os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    red_dev = torch.device("cpu") if rehearsal else dev   # where the scalars of the final reductions live
 
     strip = 4
     r = api.Renderer(make_scene(cfg), width, height, max_bounces=depth, n_sobol=n_sobol, rank=rank, world_size=world, strip_rows=strip,
@@ -130,6 +137,9 @@ def main():
         if world > 1:
             ptr, _ = r.accum_device_ptr()
             fb = ptdist.wrap_device_framebuffer(ptr, n_rows, width, dev)
+            if rehearsal:
+                torch.cuda.synchronize(dev)
+                fb = fb.cpu()
             ptdist.gather_framebuffer(fb, height, width, rank, world, strip, dst=0)
 
     if warmup == 0 and big:
@@ -154,7 +164,7 @@ def main():
     st = r.stats()
     traced_closest_local = st.rays_closest - st.rays_primary_culled       # camera rays answered by the projection never reach the kernel
     traversed_local = traced_closest_local + st.rays_any + st.rays_light_closest_traced
-    vals = torch.tensor([dt, float(st.rays), float(st.paths), float(traversed_local)], dtype=torch.float64, device=dev)
+    vals = torch.tensor([dt, float(st.rays), float(st.paths), float(traversed_local)], dtype=torch.float64, device=red_dev)
     if world > 1:
         tmax = vals[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -190,7 +200,7 @@ def main():
             "metric": "Mray/s at 1920x1080, 256 spp; achieved HBM GB/s in traversal kernel",
             "value": traversed / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": f"{what} {width}x{height}, {spp} spp, depth {depth}, NEE+MIS", "name": args.config,
                        "spp_of_configuration": spp_own,
                        "parallelism": f"rows/{world}", "mpaths_per_s": paths / dt / 1e6, "rays_per_path": rays / max(paths, 1.0),

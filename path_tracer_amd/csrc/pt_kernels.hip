@@ -73,6 +73,19 @@ namespace {
 #if PT_TWO_PHASE != 0 && PT_OCT_NODES
 #error "k_closest2 / k_closest3 stage the plain BVH blob: build PT_TWO_PHASE variants with -DPT_OCT_NODES=0"
 #endif
+// k_any with streamed lanes (a next-ray register set per lane, set-up in batches; any_body).  An experiment, off: bit-exact (82 GPU tests),
+// same-box A/B per 256-spp Cornell frame: 68.5-68.8 ms without; looks at the buffers every 1 / 2 / 3 wave-steps 73.4 / 71.7 / 74.4 ms,
+// every 4 steps 68.6-68.9 ms (set-up batches at 32 or 48 empty lanes alike).  Shadow rays are short: what the fuller lanes return, the
+// looks at the buffers and the register moves of a hand-over cost again.
+#ifndef PT_ANY_STREAM
+#define PT_ANY_STREAM 0
+#endif
+#ifndef PT_ANY_STREAM_IN
+#define PT_ANY_STREAM_IN 32
+#endif
+#ifndef PT_ANY_STREAM_STEPS
+#define PT_ANY_STREAM_STEPS 4
+#endif
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
@@ -2231,15 +2244,15 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
     // A shadow ray whose path id carries PATH_ENDS belongs to a path that died in the shading pass with nothing else owed: its
     // radiance is completed here (accumulated += path_weight * (explicit + 0), integrator.rs:231-234) instead of in a terminal pass.
     bool path_ends = false;
-    auto put_result = [&](uint32_t v) {
+    auto put_result_at = [&](uint32_t idx, bool ends, uint32_t v) {
         if (MODE == ANY_SHADOW)
         {
-            DPathRec* rec = reinterpret_cast<DPathRec*>(occluded) + out_idx;
-            if (path_ends)
+            DPathRec* rec = reinterpret_cast<DPathRec*>(occluded) + idx;
+            if (ends)
             {
                 const f3 e = v != 0u ? f3{0.0f, 0.0f, 0.0f} : xyz(rec->nee_e);
                 const f3 acc = xyz(rec->acc) + xyz(rec->nee_pw) * (e + f3{0.0f, 0.0f, 0.0f});
-                radiance[out_idx] = f4{acc.x, acc.y, acc.z, 0.0f};
+                radiance[idx] = f4{acc.x, acc.y, acc.z, 0.0f};
             }
             else if (v != 0u)
             {
@@ -2247,8 +2260,9 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 e[0] = 0.0f; e[1] = 0.0f; e[2] = 0.0f;
             }
         }
-        else occluded[out_idx] = v;
+        else occluded[idx] = v;
     };
+    auto put_result = [&](uint32_t v) { put_result_at(out_idx, path_ends, v); };
     bool in_blas = false;
 #if PT_WAVE_TIMES
     const uint32_t tw_start = (uint32_t)wall_clock64();
@@ -2256,6 +2270,83 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
 #endif
     WaveRange wr = first_range(plan, heads);
 
+#if PT_ANY_STREAM
+    // STREAMED lanes (as k_closest3, without its result registers: an any-hit ray's result is one conditional store).  Every lane holds a
+    // NEXT ray, already set up — three correctly rounded reciprocals, the root box, 32 bytes of loads: most of what a short shadow ray
+    // costs — so that set-up runs as a batch when PT_ANY_STREAM_IN lanes have none, at 50-100 % lane occupancy instead of the ~24 lanes
+    // of a refill, and a lane whose ray ends goes on with its next one within PT_ANY_STREAM_STEPS wave-steps.
+    bool nx_valid = false;
+    LaneRay nx{};
+    float nx_tmax = 0.0f, nx_te = 0.0f;
+    uint32_t nx_out = 0, nx_flags = 0; // flags: bit 0 PATH_ENDS, bit 1 origin and direction are finite
+    for (;;)
+    {
+        const bool no_more = wr.drained && wr.cur >= wr.end;
+#if PT_WAVE_TIMES
+        if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
+#endif
+        const uint64_t m_nx = __ballot(nx_valid);
+        if (!no_more && ((uint32_t)__popcll(~m_nx) >= (uint32_t)PT_ANY_STREAM_IN || __ballot(active) == 0ull))
+        {
+            const uint64_t need = ~m_nx;
+            uint32_t first;
+            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(need), first);
+            const uint32_t rank = mbcnt64(need);
+            if (!nx_valid && rank < take)
+            {
+                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0>(first + rank, plan.n);
+                const f4 a = ra[mine], bb = rb[mine];
+                const uint32_t tag = asu(bb.w);
+                if (tag != HOLE)
+                {
+                    valid_rays += 1u;
+                    const bool ends = MODE == ANY_SHADOW && (tag & PATH_ENDS) != 0u;
+                    const uint32_t idx = (MODE == ANY_HOOK) ? mine : (tag & ~PATH_ENDS);
+                    nx.o = xyz(a);
+                    nx.d = xyz(bb);
+                    nx.inv = rcp3(nx.d);
+                    nx_tmax = a.w;
+                    const bool finite = finite3(nx.o) && finite3(nx.d);
+                    // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
+                    const uint32_t nbx = OCT ? octant_of(nx.inv) * bl.oct_stride : 0u;
+                    float te;
+                    const bool ok = (nx_tmax == nx_tmax) && slab_n<OCT>(bl.nodes[nbx + 2u * root], bl.nodes[nbx + 2u * root + 1u], nx.o, nx.inv, nx_tmax, te);
+                    if (ok)
+                    {
+                        nx_valid = true;
+                        nx_out = idx;
+                        nx_flags = (ends ? 1u : 0u) | (finite ? 2u : 0u);
+                        nx_te = te;
+                    }
+                    else put_result_at(idx, ends, 0u);
+                }
+            }
+        }
+        if (!active && nx_valid)
+        {
+            w = nx;
+            t_max = nx_tmax;
+            out_idx = nx_out;
+            path_ends = (nx_flags & 1u) != 0u;
+            ray_finite = (nx_flags & 2u) != 0u;
+            if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
+            in_blas = false;
+            sp = stk.empty();
+            stk.put(sp, make_uint2(reinterpret_cast<const uint32_t*>(bl.nodes + 2u * root)[3], asu(nx_te)));
+            sp = stk.up(sp);
+            active = true;
+            nx_valid = false;
+        }
+        if (__ballot(active || nx_valid) == 0ull)
+        {
+            if (no_more) break;
+            continue; // (a batch of holes, or of rays that all missed the root box)
+        }
+#pragma unroll 1
+        for (int it = 0; it < PT_ANY_STREAM_STEPS; ++it)
+        {
+            if (!active) continue;
+#else
     for (;;)
     {
         uint64_t act = __ballot(active);
@@ -2310,6 +2401,7 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
         for (int it = 0; it < Refill<LDS_SCENE>::kStepsAny; ++it)
         {
             if (!active) continue;
+#endif
             if (in_blas && sp == blas_base) in_blas = false;
             if (sp == stk.empty())
             {

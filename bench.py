@@ -241,7 +241,8 @@ def main():
         va, lanes = kc.get("valu_active_frac"), kc.get("lanes_per_valu_instr")
         valu_busy = va * waves if (va is not None and waves) else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": f"k_closest<{'LDS' if lds_scene else 'global BVH'}, PRIMARY|WORLD>", "avg_launch_ms": avg_ms, "launches": int(launches),
+                "kernel": ("k_closest<LDS, PRIMARY> (bounce 0) + k_trace_fused<LDS> (later bounces: the world closest-hit rays, then the few BSDF-sampled NEE rays of the bounce before)"
+                           if lds_scene else "k_closest<global BVH, PRIMARY|WORLD>"), "avg_launch_ms": avg_ms, "launches": int(launches),
                 "algorithmic_bytes_per_ray": alg_per_ray, "algorithmic_bytes_source": alg_src, "rays_per_launch": rays_per_launch,
                 "closest_Mray_per_s_in_kernel": traced_closest_local / max(st.ms_trace_closest, 1e-9) / 1e3,
                 # what actually binds the kernel (profiles/r03_*_summary.md): VALU issue.  valu_busy = share of the SIMD's issue cycles that carry a VALU

@@ -73,6 +73,10 @@ namespace {
 #if PT_TWO_PHASE != 0 && PT_OCT_NODES
 #error "k_closest2 / k_closest3 stage the plain BVH blob: build PT_TWO_PHASE variants with -DPT_OCT_NODES=0"
 #endif
+// frames with fewer local pixels than this use four lanes per pixel in k_accumulate (k_accumulate<FEW_PIXELS>)
+#ifndef PT_ACC_QUAD_BELOW
+#define PT_ACC_QUAD_BELOW (1u << 30) // (whole 1080p frame: 0.675 -> 0.55 ms; beyond 2^30 pixels the thread index would overflow)
+#endif
 // k_any with streamed lanes (a next-ray register set per lane, set-up in batches; any_body).  An experiment, off: bit-exact (82 GPU tests),
 // same-box A/B per 256-spp Cornell frame: 68.5-68.8 ms without; looks at the buffers every 1 / 2 / 3 wave-steps 73.4 / 71.7 / 74.4 ms,
 // every 4 steps 68.6-68.9 ms (set-up batches at 32 or 48 empty lanes alike).  Shadow rays are short: what the fuller lanes return, the
@@ -3521,7 +3525,7 @@ void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& 
                        uint32_t write_position, uint32_t add_to_accum)
 {
     const uint32_t blocks = (rp.local_pixels + 255u) / 256u;
-    if (rp.local_pixels < (1u << 20)) hipLaunchKernelGGL(k_accumulate<true>, dim3((rp.local_pixels * 4u + 255u) / 256u), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
+    if (rp.local_pixels < (uint32_t)PT_ACC_QUAD_BELOW) hipLaunchKernelGGL(k_accumulate<true>, dim3((rp.local_pixels * 4u + 255u) / 256u), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
     else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(256), 0, s, rp, cam, wb.st, accum, position, id, write_position, add_to_accum);
 }
 void launch_store_samples(hipStream_t s, const RenderParams& rp, const WavefrontBuffers& wb, f4* out)

@@ -4,6 +4,9 @@
 //
 //   examples/headless [--width W] [--height H] [--frames N] [--bounces B] [--move] [--models DIR] [--out file.png]
 //   examples/headless --gpus N [--devices a,b,..] --spp S ...   the same scene, S samples per pixel on N GPUs of this process (pt_multi)
+//   examples/headless --render FIRST COUNT [--load-state in.bin] [--save-state out.bin] ...   samples [FIRST, FIRST + COUNT) accumulated
+//       without the temporal pass; the frame's state (accumulation, first-hit position, id history) can be saved and picked up by another
+//       process: a long render stopped and continued (pt_read_frame / pt_write_accumulation)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +24,9 @@ int main(int argc, char** argv)
     bool move = false;
     uint32_t gpus = 0, spp = 64;
     std::vector<int32_t> devices;
-    std::string models_dir = "models/cornell", out = "";
+    std::string models_dir = "models/cornell", out = "", load_state = "", save_state = "";
+    bool render_mode = false;
+    uint32_t render_first = 0, render_count = 0;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -38,6 +43,9 @@ int main(int argc, char** argv)
         else if (a == "--move") move = true;
         else if (a == "--gpus") gpus = (uint32_t)std::atoi(next("--gpus"));
         else if (a == "--spp") spp = (uint32_t)std::atoi(next("--spp"));
+        else if (a == "--render") { render_mode = true; render_first = (uint32_t)std::atoi(next("--render")); render_count = (uint32_t)std::atoi(next("--render")); }
+        else if (a == "--load-state") load_state = next("--load-state");
+        else if (a == "--save-state") save_state = next("--save-state");
         else if (a == "--devices")
         {
             const std::string list = next("--devices");
@@ -90,6 +98,38 @@ int main(int argc, char** argv)
             return 0;
         }
         Renderer renderer(scene, cam, width, height, bounces);
+        if (render_mode)
+        {
+            // checkpoint / resume: the state file is {width, height, data rgba, position xyzt, id} of the frame as it lies on the device
+            if (!load_state.empty())
+            {
+                std::FILE* f = std::fopen(load_state.c_str(), "rb");
+                uint32_t wh[2] = {0, 0};
+                Frame fr;
+                const size_t px = (size_t)width * height;
+                fr.data.resize(px * 4); fr.position.resize(px * 4); fr.id.resize(px);
+                const bool ok = f && std::fread(wh, 4, 2, f) == 2 && wh[0] == width && wh[1] == height && std::fread(fr.data.data(), 4, px * 4, f) == px * 4 &&
+                                std::fread(fr.position.data(), 4, px * 4, f) == px * 4 && std::fread(fr.id.data(), 4, px, f) == px;
+                if (f) std::fclose(f);
+                if (!ok) { std::fprintf(stderr, "cannot read a %ux%u frame state from %s\n", width, height, load_state.c_str()); return 1; }
+                renderer.write_accumulation(fr);
+            }
+            renderer.render(render_first, render_count);
+            if (!save_state.empty())
+            {
+                const Frame fr = renderer.read_frame();
+                std::FILE* f = std::fopen(save_state.c_str(), "wb");
+                const uint32_t wh[2] = {width, height};
+                const size_t px = (size_t)width * height;
+                const bool ok = f && std::fwrite(wh, 4, 2, f) == 2 && std::fwrite(fr.data.data(), 4, px * 4, f) == px * 4 && std::fwrite(fr.position.data(), 4, px * 4, f) == px * 4 &&
+                                std::fwrite(fr.id.data(), 4, px, f) == px;
+                if (f) std::fclose(f);
+                if (!ok) { std::fprintf(stderr, "cannot write %s\n", save_state.c_str()); return 1; }
+            }
+            std::printf("{\"first_sample\": %u, \"samples\": %u, \"width\": %u, \"height\": %u}\n", render_first, render_count, width, height);
+            if (!out.empty()) renderer.write_image(out);
+            return 0;
+        }
         Mat4 last_inv_proj = renderer.inv_projection();
 
         const auto t0 = std::chrono::steady_clock::now();

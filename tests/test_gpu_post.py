@@ -248,6 +248,31 @@ def test_cpp_host_driver_on_several_devices(api, oracle_mod, tmp_path, args, rcc
     assert np.array_equal(_read_png(out_png), oracle_mod.post_rgb8(acc))
 
 
+def test_cpp_host_driver_resumes_a_render_in_another_process(api, oracle_mod, tmp_path):
+    """examples/headless --render: one process renders samples [0, 3) and saves the frame state, a second process loads it and renders
+    [3, 5): its PNG holds the bytes of the oracle's samples [0, 5) — a long render stopped and continued (pt_read_frame / pt_write_accumulation)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from path_tracer_amd import build as B, scenes
+    from path_tracer_amd.scene_desc import Model, SceneDesc
+    W, H, BOUNCES = 80, 50, 5
+    exe = B.build_host_driver()
+    state, out_png = tmp_path / "state.bin", tmp_path / "resumed.png"
+    common = [exe, "--width", str(W), "--height", str(H), "--bounces", str(BOUNCES)]
+    a = subprocess.run(common + ["--render", "0", "3", "--save-state", str(state)], capture_output=True, text=True, cwd=ROOT)
+    assert a.returncode == 0, a.stderr
+    assert os.path.getsize(state) == 8 + W * H * (16 + 16 + 4)
+    b = subprocess.run(common + ["--render", "3", "2", "--load-state", str(state), "--out", str(out_png)], capture_output=True, text=True, cwd=ROOT)
+    assert b.returncode == 0, b.stderr
+    src = scenes.cornell_models()
+    sc = SceneDesc.new([Model.from_obj(os.path.join(ROOT, "models", "cornell", m.name + ".obj"), m.material) for m in src], scenes.reference_camera(W / H))
+    acc = oracle_mod.Oracle(sc).render(W, H, 5, max_bounces=BOUNCES)[0]
+    assert np.array_equal(_read_png(out_png), oracle_mod.post_rgb8(acc))
+    bad = subprocess.run(common + ["--width", "64", "--render", "3", "2", "--load-state", str(state)], capture_output=True, text=True, cwd=ROOT)
+    assert bad.returncode == 1 and "cannot read" in bad.stderr      # a state of another frame size is refused
+
+
 def test_frame_needs_the_whole_image_on_one_rank(api, cornell64):
     r = api.Renderer(cornell64, 64, 64, rank=0, world_size=2)
     with pytest.raises(api.PtError) as e:

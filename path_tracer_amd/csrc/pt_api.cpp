@@ -39,6 +39,9 @@ using namespace pt;
 #ifndef PT_SIDE_PRIORITY
 #define PT_SIDE_PRIORITY 0
 #endif
+#ifndef PT_SPLIT_MIN_PATHS
+#define PT_SPLIT_MIN_PATHS (12u << 20)
+#endif
 #ifndef PT_FUSED_TRACE
 #define PT_FUSED_TRACE 1
 #endif
@@ -892,6 +895,14 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // (A request that fits at once runs as ONE batch on one pipeline.  Cutting a small one — a rank's share of a sharded frame — in two
     // for two pipelines used to hide its launch tails (-8 %); since the tails were shortened at the source (striped tails, tapered
     // chunks) it costs 5 % instead: twice the launches, and two persistent kernels fighting for the same wave slots.)
+    // ... with one exception: BVHs in global memory.  Their rays are long, the launches end in long tails, and two half-size batches on two
+    // pipelines overlap them: 82 k-triangle mesh, 1080p: 32 spp 43.9 -> 40.6 ms, 512 spp 629.5 -> 579.8 ms (four batches of 128: 587.5,
+    // eight of 64: 594.6); 328 k mesh, 1024 spp: 1983 -> 1907 ms; nothing to gain below ~12 M paths (8 spp: 14.21 -> 14.26 ms).
+    if (!c->cfg.batch_spp && n_batches == 1 && !c->lds_scene && want_pipes >= 2 && n_samples >= 2 && (uint64_t)n_samples * act_pixels >= (uint64_t)PT_SPLIT_MIN_PATHS)
+    {
+        n_batches = 2;
+        batch = (n_samples + 1) / 2;
+    }
     uint32_t n_pipes = std::min(want_pipes, n_batches);
     if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * act_pixels * n_pipes > max_paths)
     {

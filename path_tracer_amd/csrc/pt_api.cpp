@@ -40,7 +40,10 @@ using namespace pt;
 #define PT_SIDE_PRIORITY 0
 #endif
 #ifndef PT_SPLIT_MIN_PATHS
-#define PT_SPLIT_MIN_PATHS (12u << 20)
+#define PT_SPLIT_MIN_PATHS (6u << 20)
+#endif
+#ifndef PT_PIPES4_MIN_PATHS
+#define PT_PIPES4_MIN_PATHS (~0ull) // four pipelines by default: never (see render_common); pt_config.pipelines = 4 asks for them
 #endif
 #ifndef PT_FUSED_TRACE
 #define PT_FUSED_TRACE 1
@@ -874,7 +877,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // Batches: by default the whole request stays resident when HBM allows; otherwise (or with pt_config.batch_spp) it is cut into
     // equal batches that alternate between `pipelines` wavefront pipelines on their own HIP streams, so that one batch's launch
     // tails overlap the other's launches.  ~PT_BYTES_PER_PATH of wavefront state per path; path ids are 29-bit.
-    const uint32_t want_pipes = samples_out ? 1u : std::min<uint32_t>(c->cfg.pipelines ? c->cfg.pipelines : 2u, (uint32_t)pt_ctx::kMaxPipes);
+    uint32_t want_pipes = samples_out ? 1u : std::min<uint32_t>(c->cfg.pipelines ? c->cfg.pipelines : 2u, (uint32_t)pt_ctx::kMaxPipes);
     size_t max_paths = (size_t)96 << 20;
     {
         size_t free_b = 0, total_b = 0;
@@ -895,13 +898,21 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // (A request that fits at once runs as ONE batch on one pipeline.  Cutting a small one — a rank's share of a sharded frame — in two
     // for two pipelines used to hide its launch tails (-8 %); since the tails were shortened at the source (striped tails, tapered
     // chunks) it costs 5 % instead: twice the launches, and two persistent kernels fighting for the same wave slots.)
-    // ... with one exception: BVHs in global memory.  Their rays are long, the launches end in long tails, and two half-size batches on two
-    // pipelines overlap them: 82 k-triangle mesh, 1080p: 32 spp 43.9 -> 40.6 ms, 512 spp 629.5 -> 579.8 ms (four batches of 128: 587.5,
-    // eight of 64: 594.6); 328 k mesh, 1024 spp: 1983 -> 1907 ms; nothing to gain below ~12 M paths (8 spp: 14.21 -> 14.26 ms).
-    if (!c->cfg.batch_spp && n_batches == 1 && !c->lds_scene && want_pipes >= 2 && n_samples >= 2 && (uint64_t)n_samples * act_pixels >= (uint64_t)PT_SPLIT_MIN_PATHS)
+    // ... with one exception: BVHs in global memory.  Their rays are long, the launches end in long tails, and smaller batches on several
+    // pipelines overlap them (same box, 82 k-triangle mesh at 1080p unless noted):
+    //   32 spp   one batch 43.9 ms   2 x 16 on two pipelines 40.8   4 x 8 on four 44.9
+    //   128 spp                      2 x 64: 149.1                  4 x 32: 149.3
+    //   512 spp  one batch 629.5     2 x 256: 580 (4 x 128 on TWO pipelines: 583-588)   3 x 171 on three: 572   4 x 128 on four: 561
+    //   328 k mesh, 1024 spp         2 x 512: 1903                  3 x 342: 1889       4 x 256: 1846
+    //   8 spp (4 M paths) 14.21 -> 14.26: nothing; three spheres, 8 spp (7.8 M paths): 10.46 -> 9.95 (four pipelines: 11.3)
+    // so: two pipelines from PT_SPLIT_MIN_PATHS paths on.  Four (from PT_PIPES4_MIN_PATHS on) did not hold up under bench.py: 82 k mesh at 512 spp
+    // 573 -> 588 ms, 328 k mesh at 1024 spp 1979 -> 1959 ms, three spheres at 4096^2 x 1024 spp 12.15 -> 12.43 s; off.
+    const uint64_t total_paths = (uint64_t)n_samples * act_pixels;
+    if (!samples_out && !c->cfg.pipelines && !c->lds_scene && total_paths >= (uint64_t)PT_PIPES4_MIN_PATHS) want_pipes = (uint32_t)pt_ctx::kMaxPipes;
+    if (!c->cfg.batch_spp && n_batches < want_pipes && !c->lds_scene && want_pipes >= 2 && total_paths >= (uint64_t)PT_SPLIT_MIN_PATHS)
     {
-        n_batches = 2;
-        batch = (n_samples + 1) / 2;
+        n_batches = std::min<uint32_t>(want_pipes, n_samples);
+        batch = (n_samples + n_batches - 1) / n_batches;
     }
     uint32_t n_pipes = std::min(want_pipes, n_batches);
     if (!c->cfg.batch_spp && n_batches > 1 && (uint64_t)batch * act_pixels * n_pipes > max_paths)

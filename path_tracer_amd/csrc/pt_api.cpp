@@ -42,6 +42,9 @@ using namespace pt;
 #ifndef PT_SPLIT_MIN_PATHS
 #define PT_SPLIT_MIN_PATHS (6u << 20)
 #endif
+#ifndef PT_SPLIT_MIN_PATHS_LDS
+#define PT_SPLIT_MIN_PATHS_LDS (100u << 20)
+#endif
 #ifndef PT_PIPES4_MIN_PATHS
 #define PT_PIPES4_MIN_PATHS (~0ull) // four pipelines by default: never (see render_common); pt_config.pipelines = 4 asks for them
 #endif
@@ -909,7 +912,10 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // 573 -> 588 ms, 328 k mesh at 1024 spp 1979 -> 1959 ms, three spheres at 4096^2 x 1024 spp 12.15 -> 12.43 s; off.
     const uint64_t total_paths = (uint64_t)n_samples * act_pixels;
     if (!samples_out && !c->cfg.pipelines && !c->lds_scene && total_paths >= (uint64_t)PT_PIPES4_MIN_PATHS) want_pipes = (uint32_t)pt_ctx::kMaxPipes;
-    if (!c->cfg.batch_spp && n_batches < want_pipes && !c->lds_scene && want_pipes >= 2 && total_paths >= (uint64_t)PT_SPLIT_MIN_PATHS)
+    // LDS-resident BVHs gain only on very large requests (with round 3's launch structure): the 133 M-path headline frame 68.3 -> 67.2 ms
+    // (bench.py, three interleaved repeats), mixed materials at 66 M paths 42.9 -> 42.3 ms, but rank 0's half of the sharded frame (66 M
+    // paths) 35.0 -> 35.7 ms and its quarter +-0: from PT_SPLIT_MIN_PATHS_LDS paths on.
+    if (!c->cfg.batch_spp && n_batches < want_pipes && want_pipes >= 2 && total_paths >= (c->lds_scene ? (uint64_t)PT_SPLIT_MIN_PATHS_LDS : (uint64_t)PT_SPLIT_MIN_PATHS))
     {
         n_batches = std::min<uint32_t>(want_pipes, n_samples);
         batch = (n_samples + n_batches - 1) / n_batches;

@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--batch-spp", type=int, default=0)
+    ap.add_argument("--pipelines", type=int, default=0, help="wavefront pipelines (0: the library's choice; 1: one batch after another, what the profile passes use so that kernel durations do not overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-ms", action="store_true", help="skip the extra untimed step that times every kernel category (profiling runs: counters then cover the timed steps only)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every launch INSIDE the timed region (diagnostic, slower)")
@@ -126,7 +127,7 @@ def main():
 
     strip = 4
     r = api.Renderer(make_scene(cfg), width, height, max_bounces=depth, n_sobol=n_sobol, rank=rank, world_size=world, strip_rows=strip,
-                     batch_spp=args.batch_spp, device=dev.index, flags=api.FLAG_TIMING | (api.FLAG_TIMING_ALL if args.time_all_kernels else 0))
+                     batch_spp=args.batch_spp, pipelines=args.pipelines, device=dev.index, flags=api.FLAG_TIMING | (api.FLAG_TIMING_ALL if args.time_all_kernels else 0))
     stream = torch.cuda.current_stream(dev)
     r.set_stream(stream.cuda_stream)
     n_rows = len(r.local_rows())

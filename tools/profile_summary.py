@@ -43,7 +43,7 @@ def main(src, tag):
     ksf = find(src, "kt", "*kernel_stats.csv")
     ks = pd.read_csv(ksf)
     ks["kernel"] = ks["Name"].map(short)
-    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py {args} --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-ms` (two steps)", "",
+    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py {args} --pipelines 1 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-ms` (two steps)", "",
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for _, r in ks.iterrows():
         lines.append(f"| {r['kernel']} | {r['Calls']} | {r['TotalDurationNs'] / 1e6:.2f} | {r['AverageNs'] / 1e3:.1f} | {r['Percentage']:.2f} |")
@@ -67,7 +67,7 @@ def main(src, tag):
         g = pm.groupby(["kernel", "Counter_Name"])["Counter_Value"].sum().unstack()
         n = pm.groupby(["kernel", "Counter_Name"])["Dispatch_Id"].nunique().unstack()
         spp_p = pmc_bench["config"]["workload"].split(" spp")[0].split(", ")[-1] if pmc_bench else "?"
-        lines += ["", f"## PMC passes (`--pmc`, one pass per counter group; bench.py {args} --steps 1 --warmup 0, {spp_p} spp)", "",
+        lines += ["", f"## PMC passes (`--pmc`, one pass per counter group; bench.py {args} --pipelines 1 --steps 1 --warmup 0, {spp_p} spp)", "",
                   "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                   "(MI355X_MICROARCH.md §HBM), so read bytes below = 2 x FETCH_SIZE x 1024.", ""]
         cols = [c for c in ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",

@@ -2143,12 +2143,15 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
     // PTMI_STEP_STATS_BASE=16: the second group of eight words (PT_STEP_STATS=2 builds: section times)
     const char* base_env = std::getenv("PTMI_STEP_STATS_BASE");
     const uint32_t base = base_env && std::atoi(base_env) == 16 ? 16u : 8u;
+    // PTMI_STEP_STATS_QUEUE=shadow: the shadow-ray launches' statistics (k_any) instead of the closest-hit launches'
+    const char* q_env = std::getenv("PTMI_STEP_STATS_QUEUE");
+    const uint32_t which_queue = q_env && q_env[0] == 's' ? (uint32_t)HEADS_SHADOW : (uint32_t)HEADS_CLOSEST;
     for (uint32_t r = 0; r < rows; ++r)
     {
         uint32_t* o = rows8 + 8 * r;
         std::memset(o, 0, 32);
         if (r >= pp.busy_rows) continue; // not read back: the batch ended before this bounce
-        const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue + HEADS_CLOSEST * kHeadWordsPerQueue;
+        const uint32_t* hrow = pp.h_heads + (size_t)r * HEADS_PER_ROW * kHeadWordsPerQueue + which_queue * kHeadWordsPerQueue;
         for (uint32_t g = 0; g < kQueueHeads; ++g)
             for (uint32_t k = 0; k < 8; ++k) o[k] += hrow[g * kHeadStrideWords + base + k];
     }

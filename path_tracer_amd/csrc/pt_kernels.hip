@@ -2272,6 +2272,9 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
     const uint32_t tw_start = (uint32_t)wall_clock64();
     uint32_t tw_drained = 0u;
 #endif
+#if PT_STEP_STATS
+    uint32_t st_iter = 0, st_lane_active = 0, st_lane_inst = 0, st_lane_branch = 0, st_lane_leaf = 0, st_wave_inst = 0, st_wave_branch = 0, st_wave_leaf = 0;
+#endif
     WaveRange wr = first_range(plan, heads);
 
 #if PT_ANY_STREAM
@@ -2404,6 +2407,12 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
 #pragma unroll 1
         for (int it = 0; it < Refill<LDS_SCENE>::kStepsAny; ++it)
         {
+#if PT_STEP_STATS
+            {
+                const uint64_t am = __ballot(active);
+                if (am != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(am); }
+            }
+#endif
             if (!active) continue;
 #endif
             if (in_blas && sp == blas_base) in_blas = false;
@@ -2417,6 +2426,9 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             const uint2 e = stk.get(sp);                     // (link, entry distance) of a node whose box the ray meets
             uint32_t link = e.x;
             float t_enter = asf(e.y);
+#if PT_STEP_STATS
+            { const bool x = (link >> NODE_KIND_SHIFT) == NODE_INSTANCE; const uint64_t m = __ballot(x); st_lane_inst += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_inst += 1u; }
+#endif
             if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
             {
                 // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
@@ -2430,6 +2442,9 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 link = r0.w;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+#if PT_STEP_STATS
+            { const bool x = kind == NODE_BRANCH; const uint64_t m = __ballot(x); st_lane_branch += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_branch += 1u; }
+#endif
             // up to PT_BRANCH_LEVELS_ANY levels per step: the child that would be popped next (right if met, else left) is expanded or
             // tested at once instead of going through the stack (the kernel pays per wave-step, profiles/r02_step_stats_cornell.md)
 #pragma unroll 1
@@ -2456,6 +2471,9 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                     else { stk.put(sp, next); sp = stk.up(sp); }
                 }
             }
+#if PT_STEP_STATS
+            { const bool x = (kind & 1u) != 0u; const uint64_t m = __ballot(x); st_lane_leaf += x ? 1u : 0u; if (m != 0ull && lane_id() == (uint32_t)__builtin_ctzll(m)) st_wave_leaf += 1u; }
+#endif
             if (kind & 1u)
             {
                 uint32_t first, count;
@@ -2474,6 +2492,22 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             }
         }
     }
+#if PT_STEP_STATS
+    // words 8..15 of the shadow queue's cursor lines, as k_closest's (tools/step_stats.py any): wave-steps, lanes active, lanes taking the
+    // instance / branch / leaf section, wave-steps in which some lane took it
+    if (MODE == ANY_SHADOW)
+    {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        if (lane_id() == 0u) { atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); }
+        uint32_t x = st_lane_inst, y = st_lane_branch, z = st_lane_leaf;
+        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); z += __shfl_xor(z, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 10, x); atomicAdd(line + 11, y); atomicAdd(line + 12, z); }
+        x = st_wave_inst; y = st_wave_branch; z = st_wave_leaf;
+        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); z += __shfl_xor(z, off); }
+        if (lane_id() == 0u) { atomicAdd(line + 13, x); atomicAdd(line + 14, y); atomicAdd(line + 15, z); }
+    }
+#endif
     if (MODE == ANY_SHADOW) add_tally(heads, valid_rays, HEAD_TALLY0);
 #if PT_WAVE_TIMES
     if (MODE == ANY_SHADOW && lane_id() == 0u && g_any_times)

@@ -6,6 +6,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from path_tracer_amd import api, scenes
+if len(sys.argv) > 1 and sys.argv[1] == "any":      # step_stats.py any [scene] [spp]: the shadow-ray kernel (k_any) instead
+    os.environ["PTMI_STEP_STATS_QUEUE"] = "shadow"
+    del sys.argv[1]
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 kw = {}
@@ -16,13 +19,13 @@ r = api.Renderer(getattr(scenes, name)(W, H, **kw), W, H, max_bounces=8, pipelin
 r.render_device(0, spp); r.synchronize()
 st = r.last_batch_step_stats().astype(np.float64)
 ctr = r.last_batch_counters().astype(np.float64)
-print(f"# step statistics of k_closest, scene {name} {kw}, 1920x1080, {spp} spp, depth 8 (one batch)")
+print(f"# step statistics of {'k_any (shadow rays cast by the bounce)' if os.environ.get('PTMI_STEP_STATS_QUEUE') else 'k_closest'}, scene {name} {kw}, 1920x1080, {spp} spp, depth 8 (one batch)")
 print("| bounce | rays | wave-steps | steps per ray (lane-steps / rays) | lanes active per wave-step | instance: lanes per executing wave-step (share of wave-steps) | branch | triangle leaf |")
 print("|---|---|---|---|---|---|---|---|")
 tot = np.zeros(8); rays_tot = 0
 for b in range(len(st)):
     it, act, li, lb, ll, wi, wb, wl = st[b]
-    rays = ctr[b][13]
+    rays = ctr[b][14] if os.environ.get("PTMI_STEP_STATS_QUEUE") else ctr[b][13]
     if it == 0: continue
     tot += st[b]; rays_tot += rays
     f = lambda l, w: f"{l / max(w, 1):.1f} ({w / it:.2f})"

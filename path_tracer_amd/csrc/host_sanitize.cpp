@@ -5,6 +5,8 @@
 //   host_sanitize obj <file>...        Model::new(path) + Scene::new for each file (parse errors are an expected outcome)
 //   host_sanitize walk <events> <seed> Camera::input random walk with create_ray after every event
 //   host_sanitize png <w> <h> <file>   encode a test image
+//   host_sanitize soup <n> <seed>      Scene::new over n random triangles (PTMI_BUILD_THREADS forks the SAH sweep: also built with
+//                                      -fsanitize=thread by `make host-tsan`); prints a checksum of the BLAS arena
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -81,6 +83,38 @@ int main(int argc, char** argv)
             acc += d[0] + d[1] + d[2] + m[5];
         }
         std::printf("{\"checksum\": %.6f}\n", acc);
+        return 0;
+    }
+    if (cmd == "soup" && argc >= 4)
+    {
+        HostScene sc;
+        const int mat = light_scene(sc);
+        if (mat < 0) return 3;
+        const uint32_t n = (uint32_t)std::atoi(argv[2]);
+        uint64_t s = std::strtoull(argv[3], nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+        auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 40) & 0xffff) / 65535.0f; };
+        std::vector<float> p((size_t)n * 9), nr((size_t)n * 9, 0.0f);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            const float c[3] = {rnd() * 200.0f - 100.0f, rnd() * 200.0f - 100.0f, rnd() * 200.0f - 100.0f};
+            for (int k = 0; k < 9; ++k) p[(size_t)i * 9 + k] = c[k % 3] + rnd() * 4.0f - 2.0f;
+            for (int k = 0; k < 3; ++k) nr[(size_t)i * 9 + k * 3 + 1] = 1.0f;
+        }
+        if (sc.add_model(p.data(), nr.data(), n, mat, kIdentity, 1) < 0) return 4;
+        std::string err;
+        if (sc.build(&err) != 0) { std::printf("{\"error\": \"%s\"}\n", err.c_str()); return 0; }
+        const HostBlas& b = sc.blas.back();
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
+        for (const HostNode& nd : b.nodes)
+        {
+            uint32_t w[6];
+            std::memcpy(w, &nd.box, sizeof(w));
+            for (uint32_t v : w) mix(v);
+            mix(nd.kind); mix(nd.a); mix(nd.b);
+        }
+        for (uint32_t v : b.prim_ids) mix(v);
+        std::printf("{\"nodes\": %zu, \"depth\": %u, \"arena\": \"%016llx\"}\n", b.nodes.size(), b.depth, (unsigned long long)h);
         return 0;
     }
     if (cmd == "png" && argc >= 5)

@@ -9,11 +9,14 @@
 #include "pt_scene.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <system_error>
+#include <thread>
 #include <utility>
 
 namespace pt {
@@ -81,15 +84,28 @@ xf34 inverse_affine(const xf34& a) // glam Affine3A::inverse
     return xf34{mi, -mul(mi, a.t)};
 }
 
-// SAH sweep builder over a contiguous span of (box, primitive) records.
+// SAH sweep builder over a contiguous span of (box, primitive) records.  The tree is the reference's, node for node (tests/test_host.py
+// compares the arena with the oracle's direct restatement); what differs is how it is reached:
+//  * the reference folds a box over each side of every candidate split (64 x n joins per node, blas_bvh.rs:96-110).  The left boxes
+//    are running prefixes of one forward fold - the same joins in the same order.  The right boxes come from one reverse fold
+//    join(item, suffix): `a < b ? a : b` keeps the later operand on a tie, so with the item first a +0 / -0 tie resolves to the later
+//    item exactly as the forward fold over the same items does, and all other finite or infinite values do not depend on the order.
+//    A NaN does (the forward fold forgets everything before it): a span holding one takes the direct evaluation - add_model
+//    refuses non-finite vertices, so that branch only keeps the builder free of preconditions;
+//  * the two children of a large node are built by two threads into arenas of their own and spliced in the reference's post-order.
 struct SweepItem { HostBox box; uint32_t prim; };
+struct alignas(128) SweepArena { std::vector<HostNode> nodes; std::vector<uint32_t> prim_ids; };   // two threads' arenas never share a cache line
 struct SweepBuilder
 {
-    HostBlas& out;
     std::vector<SweepItem>& items;
     static constexpr size_t kBins = 64;             // DESIRED_BINS       blas_bvh.rs:13
     static constexpr float kTraversal = 1.0f;       // TRAVERSAL_COST     blas_bvh.rs:15
     static constexpr float kIntersect = 2.0f;       // INTERSECTION_COST  blas_bvh.rs:16
+    static constexpr size_t kForkSpan = 4096;       // smaller nodes are not worth a thread
+
+    std::vector<uint64_t> keys;                     // sort scratch, indexed like `items` (threads work on disjoint spans)
+    std::vector<SweepItem> moved;
+    explicit SweepBuilder(std::vector<SweepItem>& it) : items(it), keys(it.size()), moved(it.size()) {}
 
     HostBox span_box(size_t lo, size_t hi) const                                        // blas_bvh.rs:28-33
     {
@@ -97,10 +113,39 @@ struct SweepBuilder
         for (size_t i = lo; i < hi; ++i) b = box_join(b, items[i].box);
         return b;
     }
-    uint32_t emit(const HostNode& n) { out.nodes.push_back(n); return (uint32_t)out.nodes.size() - 1; }
+    // The reference's sort is stable and compares box minima with total_cmp (glidesort, blas_bvh.rs:86-91).  A stable sort by key
+    // is a sort by (key, position), and those pairs are distinct: an ordinary in-place sort of 64-bit words, no allocation per node.
+    void sort_span(size_t lo, size_t hi, int axis)
+    {
+        for (size_t i = lo; i < hi; ++i)
+            keys[i] = ((uint64_t)((uint32_t)total_order_key(axis_of(items[i].box.mn, axis)) ^ 0x80000000u) << 32) | (uint64_t)(i - lo);
+        std::sort(keys.begin() + lo, keys.begin() + hi);
+        for (size_t i = lo; i < hi; ++i) moved[i] = items[lo + (size_t)(uint32_t)keys[i]];
+        std::copy(moved.begin() + lo, moved.begin() + hi, items.begin() + lo);
+    }
+    static bool has_nan(const HostBox& b)
+    {
+        auto nan = [](float x) { return x != x; };
+        return nan(b.mn.x) || nan(b.mn.y) || nan(b.mn.z) || nan(b.mx.x) || nan(b.mx.y) || nan(b.mx.z);
+    }
+    static uint32_t emit(SweepArena& out, const HostNode& n) { out.nodes.push_back(n); return (uint32_t)out.nodes.size() - 1; }
+    // append a finished subtree (arena-local links) to `out`; returns the subtree root's index there
+    static uint32_t splice(SweepArena& out, const SweepArena& sub, uint32_t sub_root)
+    {
+        const uint32_t node_base = (uint32_t)out.nodes.size(), prim_base = (uint32_t)out.prim_ids.size();
+        out.prim_ids.insert(out.prim_ids.end(), sub.prim_ids.begin(), sub.prim_ids.end());
+        out.nodes.reserve(out.nodes.size() + sub.nodes.size());
+        for (HostNode n : sub.nodes)
+        {
+            if (n.kind == NODE_BRANCH) { n.a += node_base; n.b += node_base; }
+            else n.a += prim_base;
+            out.nodes.push_back(n);
+        }
+        return sub_root + node_base;
+    }
 
-    // returns (node id); depth_out = nodes on the longest path below and including this node
-    uint32_t run(size_t lo, size_t hi, int parent_axis, uint32_t* depth_out)
+    // returns (node id in `out`); depth_out = nodes on the longest path below and including this node
+    uint32_t run(SweepArena& out, size_t lo, size_t hi, int parent_axis, uint32_t* depth_out, int fork_levels)
     {
         const size_t span = hi - lo;
         if (span == 1)                                                                   // LeafSingle  blas_bvh.rs:67-75
@@ -108,25 +153,38 @@ struct SweepBuilder
             uint32_t first = (uint32_t)out.prim_ids.size();
             out.prim_ids.push_back(items[lo].prim);
             *depth_out = 1;
-            return emit(HostNode{items[lo].box, NODE_TRIS, first, 1});
+            return emit(out, HostNode{items[lo].box, NODE_TRIS, first, 1});
         }
-        const HostBox bb = span_box(lo, hi);
+        HostBox bb = box_empty();
+        bool any_order = true;
+        for (size_t i = lo; i < hi; ++i)
+        {
+            bb = box_join(bb, items[i].box);
+            any_order = any_order && !has_nan(items[i].box);
+        }
         const float bb_sa = box_area(bb);
         const int axis = box_longest_axis(bb);
-        if (axis != parent_axis)                                                         // blas_bvh.rs:86-91 (glidesort: stable, total_cmp)
-        {
-            std::stable_sort(items.begin() + lo, items.begin() + hi, [axis](const SweepItem& l, const SweepItem& r) {
-                return total_order_key(axis_of(l.box.mn, axis)) < total_order_key(axis_of(r.box.mn, axis));
-            });
-        }
+        if (axis != parent_axis) sort_span(lo, hi, axis);                                // blas_bvh.rs:86-91
         const size_t bin = std::max<size_t>(span / kBins, 1);
-        const size_t n_candidates = span / bin - 1;
-        size_t best_j = 0;
+        const size_t n_candidates = span / bin - 1;                                      // <= 2 * kBins - 2
+        float right_area[2 * kBins];
+        if (any_order)
+        {
+            HostBox suffix = box_empty();
+            for (size_t i = span; i-- > bin;)
+            {
+                suffix = box_join(items[lo + i].box, suffix);               // ties (a zero of either sign) keep the later item, as the forward fold does
+                if (i % bin == 0 && i / bin <= n_candidates) right_area[i / bin - 1] = box_area(suffix);
+            }
+        }
+        size_t best_j = 0, done = 0;
         float best_cost = 0.0f;
+        HostBox prefix = box_empty();
         for (size_t c = 0; c < n_candidates; ++c)                                        // blas_bvh.rs:96-110
         {
             const size_t j = (c + 1) * bin;
-            const float la = box_area(span_box(lo, lo + j)), ra = box_area(span_box(lo + j, hi));
+            for (; done < j; ++done) prefix = box_join(prefix, items[lo + done].box);
+            const float la = box_area(prefix), ra = any_order ? right_area[c] : box_area(span_box(lo + j, hi));
             const float cost = kTraversal + ((float)j * la + (float)(span - j) * ra) * kIntersect / bb_sa;
             // min_by(total_cmp): first of equal minima wins
             if (c == 0 || total_order_key(cost) < total_order_key(best_cost)) { best_cost = cost; best_j = j; }
@@ -137,13 +195,37 @@ struct SweepBuilder
             uint32_t first = (uint32_t)out.prim_ids.size();
             for (size_t i = lo; i < hi; ++i) out.prim_ids.push_back(items[i].prim);
             *depth_out = 1;
-            return emit(HostNode{bb, NODE_TRIS, first, (uint32_t)span});
+            return emit(out, HostNode{bb, NODE_TRIS, first, (uint32_t)span});
         }
-        uint32_t dl = 0, dr = 0;
-        const uint32_t left = run(lo, lo + best_j, axis, &dl);                           // blas_bvh.rs:125-133
-        const uint32_t right = run(lo + best_j, hi, axis, &dr);
+        uint32_t dl = 0, dr = 0, left = 0, right = 0;                                    // blas_bvh.rs:125-133
+        bool forked = false;
+        if (fork_levels > 0 && span >= kForkSpan)
+        {
+            SweepArena la, ra;
+            try
+            {
+                la.nodes.reserve(2 * best_j); la.prim_ids.reserve(best_j);
+                ra.nodes.reserve(2 * (span - best_j)); ra.prim_ids.reserve(span - best_j);
+                std::thread t([&] { left = run(la, lo, lo + best_j, axis, &dl, fork_levels - 1); });
+                forked = true;
+                try { right = run(ra, lo + best_j, hi, axis, &dr, fork_levels - 1); }
+                catch (...) { t.join(); throw; }
+                t.join();
+            }
+            catch (const std::system_error&) {}                                          // no thread to be had: build the children in turn
+            if (forked)
+            {
+                left = splice(out, la, left);
+                right = splice(out, ra, right);
+            }
+        }
+        if (!forked)
+        {
+            left = run(out, lo, lo + best_j, axis, &dl, 0);
+            right = run(out, lo + best_j, hi, axis, &dr, 0);
+        }
         *depth_out = 1 + std::max(dl, dr);
-        return emit(HostNode{bb, NODE_BRANCH, left, right});
+        return emit(out, HostNode{bb, NODE_BRANCH, left, right});
     }
 };
 
@@ -375,8 +457,21 @@ void HostScene::build_blas(HostBlas& out, const HostModel& m)                   
         out.tris.push_back(make_triangle(&m.positions[(size_t)i * 9], &m.normals[(size_t)i * 9]));
         items[i] = SweepItem{triangle_box(out.tris.back()), i};
     }
-    SweepBuilder sb{out, items};
-    out.root = sb.run(0, items.size(), 4, &out.depth);                                   // last_split_axis = 4  blas.rs:191
+    const auto tt0 = std::chrono::steady_clock::now();
+    SweepBuilder sb{items};
+    SweepArena arena;
+    arena.nodes.reserve(2 * items.size());
+    arena.prim_ids.reserve(items.size());
+    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);               // PTMI_BUILD_THREADS overrides (1 = build in the caller's thread)
+    if (const char* e = std::getenv("PTMI_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(atoi(e), 64));
+    int fork_levels = 0;                                                                 // 2^levels builder threads
+    for (unsigned t = threads; t > 1; t >>= 1) ++fork_levels;
+    out.root = sb.run(arena, 0, items.size(), 4, &out.depth, fork_levels);               // last_split_axis = 4  blas.rs:191
+    out.nodes.assign(arena.nodes.begin(), arena.nodes.end());                            // exact size; the arena was reserved for the worst case
+    out.prim_ids = std::move(arena.prim_ids);
+    if (m.n_tris >= 1024 && std::getenv("PTMI_DEBUG_BUILD"))
+        fprintf(stderr, "[ptmi]  BLAS of %u triangles: %zu nodes, depth %u, SAH sweep %.1f ms on up to %d threads\n", m.n_tris, out.nodes.size(), out.depth,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(), 1 << fork_levels);
 }
 
 void HostScene::build_tlas(HostTlas& out, const std::vector<uint32_t>& model_ids)       // TLAS::new tlas.rs:24-53
@@ -461,8 +556,13 @@ void HostScene::build_lights()                                                  
 int HostScene::build(std::string* err)                                                  // Scene::new  scene.rs:21-35
 {
     if (models.empty()) { if (err) *err = "no models"; return -3; }
+    const bool dbg = std::getenv("PTMI_DEBUG_BUILD") != nullptr;                          // stage times of Scene::new on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     blas.resize(models.size());
     for (size_t i = 0; i < models.size(); ++i) build_blas(blas[i], models[i]);
+    const auto t1 = now();
     std::vector<uint32_t> all(models.size()), emissive;
     std::iota(all.begin(), all.end(), 0u);
     for (uint32_t i = 0; i < models.size(); ++i)
@@ -470,7 +570,9 @@ int HostScene::build(std::string* err)                                          
     build_tlas(world, all);
     build_tlas(lights, emissive);
     build_lights();
+    const auto t2 = now();
     int r = flatten(err);
+    if (dbg) fprintf(stderr, "[ptmi] scene build: BLAS %.1f ms, TLAS + lights %.1f ms, flatten %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     built = (r == 0);
     return r;
 }

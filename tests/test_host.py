@@ -72,6 +72,42 @@ def test_host_builders_match_oracle(api, oracle_mod, scene_name):
         assert_bit_equal(a[1], b[1], "ray direction")
 
 
+def _signed_zero_soup(n, seed):
+    """triangles on a coarse lattice that holds +0 and -0: many equal sort keys, many zero bounds of either sign"""
+    rng = np.random.default_rng(seed)
+    lattice = np.array([-2.0, -1.0, -0.0, 0.0, 1.0, 3.0], np.float32)
+    p = lattice[rng.integers(0, lattice.size, (n, 3, 3))]
+    p[:, 1] += np.float32(0.5) * (p[:, 1] == p[:, 0])          # no zero-length first edge (a NaN plane is refused by neither side, but is not the point here)
+    nr = np.zeros((n, 3, 3), np.float32)
+    nr[..., 1] = 1.0
+    return p, nr
+
+
+@pytest.mark.parametrize("threads", ["1", "8"])
+@pytest.mark.parametrize("case", ["signed_zero_soup", "displaced_sphere_82k"])
+def test_sweep_builder_is_the_reference_tree_whatever_the_thread_count(api, oracle_mod, monkeypatch, case, threads):
+    """libptmi reaches the SAH sweep tree of blas_bvh.rs:62-136 with prefix / suffix folds, a keyed sort and forked subtrees; the oracle
+    evaluates the reference's loops as written.  Same arena, same leaf order, same boxes to the bit - including the sign of a zero bound."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Lambertian, Model, SceneDesc
+    monkeypatch.setenv("PTMI_BUILD_THREADS", threads)
+    if case == "signed_zero_soup":
+        p, nr = _signed_zero_soup(9000, 11)
+        sc = SceneDesc.new([Model.new(p, nr, Lambertian.new((0.5, 0.5, 0.5)), None)], scenes.reference_camera(1.0))
+        which = 0
+    else:
+        sc = scenes.cornell_mesh(64, 64, level=6)
+        which = max(range(len(sc.models)), key=lambda i: sc.models[i].positions.shape[0])
+    r = api.Renderer(sc, 64, 64)
+    o = oracle_mod.Oracle(sc)
+    a, b = r.blas_dump(which), o.blas_dump(which)
+    assert a["kind"].size > sc.models[which].positions.shape[0] // 8
+    if case == "signed_zero_soup":
+        boxes = a["boxes"].view(np.uint32)
+        assert (boxes == 0x80000000).any() and (boxes == 0).any()   # both zeros made it into node bounds
+    _cmp(a, b, case)
+
+
 def test_non_rigid_instance_is_rejected(api, oracle_mod):
     """model.rs:40-44 asserts scale == 1: PT_ERR_NONRIGID instead of a panic."""
     from path_tracer_amd import scenes

@@ -67,3 +67,19 @@ def test_camera_walk_and_png_encoder(exe, tmp_path):
     assert '"bytes": 172800' in _run([exe, "png", "320", "180", str(tmp_path / "a.png")])
     assert "bytes" in _run([exe, "png", "1", "1", str(tmp_path / "b.png")])
     assert "error" in _run([exe, "png", "8", "8", str(tmp_path / "no_dir" / "c.png")])
+
+
+def test_forked_sweep_builder_under_asan_and_tsan(exe):
+    """The SAH sweep forks its subtrees onto threads (PTMI_BUILD_THREADS): no race, no bad access, and the arena does not depend on
+    the thread count."""
+    import json
+    r = subprocess.run(["make", "-C", CSRC, "host-tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    arenas = set()
+    for binary in (exe, EXE + "_tsan"):
+        for threads in ("1", "2", "16"):
+            env = dict(ENV, PTMI_BUILD_THREADS=threads, TSAN_OPTIONS="halt_on_error=1:exitcode=97")
+            r = subprocess.run([binary, "soup", "30000", "5"], capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (binary, threads, r.returncode, r.stderr[-3000:])
+            arenas.add(json.loads(r.stdout.strip().split("\n")[-1])["arena"])
+    assert len(arenas) == 1, arenas

@@ -674,6 +674,10 @@ int HostScene::flatten(std::string* err)
 
     uint32_t max_blas_depth = 0;
     std::vector<uint32_t> blas_root_at(blas.size(), MISS_ID);
+    f.tri_isect.reserve(tri_cursor);
+    f.tri_shade.reserve(tri_cursor);
+    f.tri_pos.reserve(tri_cursor);
+    f.tri_orig.reserve(tri_cursor);
     for (size_t i = 0; i < blas.size(); ++i)
     {
         const HostBlas& bl = blas[i];

@@ -51,12 +51,6 @@ using namespace pt;
 #ifndef PT_FUSED_TRACE
 #define PT_FUSED_TRACE 1
 #endif
-#ifndef PT_MERGE_TERMINAL_BELOW
-// Batches of fewer paths: the terminal pass of a bounce rides in its first surface launch (batch_bounce).  Same-box A/B, merged against
-// apart: 1-spp interactive frame 1.35 -> 1.305 ms, 1/8 share -0.5 %, 1/4 and 1/2 shares and the meshes +-0.3 %, the whole frame on two
-// pipelines 67.9 -> 70.2 ms (the other pipeline's traversal launch gets its wave slots later) - so only where launches are all there is.
-#define PT_MERGE_TERMINAL_BELOW (16u << 20)
-#endif
 #ifndef PT_TRACE_BLOCKS_PER_CU_MAX
 #define PT_TRACE_BLOCKS_PER_CU_MAX 8
 #endif
@@ -640,7 +634,7 @@ struct BatchRun
     TraceLaunch tl{}, tl_side{};
     hipStream_t s = nullptr;
     uint32_t rows = 0, shade_blocks = 1, last_row = 0, count = 0, cleared_rows = 0;
-    bool nee = false, side_busy = false, stopped = false, write_position = false, aux_with_samples = false, fused = false, merge_terminal = false;
+    bool nee = false, side_busy = false, stopped = false, write_position = false, aux_with_samples = false, fused = false;
     int nee_err = PT_OK;
     f4* samples_out = nullptr;
     hipEvent_t after = nullptr;
@@ -717,9 +711,6 @@ int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32
     // frame 1.24 -> 1.18 ms; BVHs in global memory lose 3 % (82 k mesh 14.2 -> 14.65 ms, 328 k 25.4 -> 26.3 ms: their NEE rays are long and
     // used to overlap the shadow-ray launch), so only the former.  Per-launch event timing (PT_FLAG_TIMING_ALL) keeps the launches apart.
     br.fused = PT_FUSED_TRACE != 0 && c->lds_scene && !(g.flags & PT_FLAG_TIMING_ALL);
-    // PTMI_MERGE_TERMINAL_BELOW=<million paths> overrides the threshold (0: never) for A/B runs
-    static const uint64_t merge_below = [] { const char* e = std::getenv("PTMI_MERGE_TERMINAL_BELOW"); return e ? (uint64_t)std::strtoull(e, nullptr, 10) << 20 : (uint64_t)PT_MERGE_TERMINAL_BELOW; }();
-    br.merge_terminal = (uint64_t)rp.n_paths < merge_below;
     return PT_OK;
 }
 
@@ -787,17 +778,8 @@ int batch_bounce(BatchRun& br, uint32_t b)
         { Timer t(c, pp, s, T_WORLD); launch_trace_world(s, br.tl, wb, b, br.rp, br.cam, br.env); }
         batch_join_side(br);
     }
-    // the terminal pass rides at the end of the first surface class's launch (disjoint paths, different queues): one launch less per bounce
-    uint32_t carrier = Q_TERMINAL;
-    if (br.merge_terminal && c->class_present[Q_TERMINAL])
-        for (uint32_t q = Q_COUNT; q-- > 1u;)
-            if (c->class_present[q]) carrier = q;
     for (uint32_t q = 0; q < Q_COUNT; ++q)
-    {
-        if (!c->class_present[q] || (q == Q_TERMINAL && carrier != Q_TERMINAL)) continue;
-        Timer t(c, pp, s, T_SHADE);
-        launch_shade(s, q, c->sv, br.rp, wb, b, br.shade_blocks, br.cam, br.env, q == carrier && carrier != Q_TERMINAL);
-    }
+        if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, br.rp, wb, b, br.shade_blocks, br.cam, br.env); }
     // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
     if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
     {

@@ -63,7 +63,7 @@ void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // shading of bounce b for one queue class
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env, bool with_terminal = false);
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env);
 // accum[pixel] += sum over batch samples in order of (finalised rgb, 1); position/id of the last samples
 void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
                        uint32_t write_position, uint32_t add_to_accum);

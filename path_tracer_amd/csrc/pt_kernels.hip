@@ -2716,13 +2716,10 @@ __device__ __forceinline__ void resolve_nee(const SceneView& sv, const ShadeIO& 
 
 // ------------------------------------------------------------------------------------------------ shading
 // Q_TERMINAL: misses (integrator.rs:254-269), emissive hits (:207-214) and paths that already ended but still owe an NEE resolve.
-// `block` of `n_blocks` workgroups: a launch of its own (k_shade_terminal), or the workgroups a surface launch carries past its own
-// (k_shade_surface, term_blocks) - the two passes of a bounce touch disjoint paths and different queues.
-__device__ __forceinline__ void shade_terminal_body(const SceneView& sv, const RenderParams& rp, const ShadeIO& io, const uint32_t bounce, const uint32_t block,
-                                                    const uint32_t n_blocks)
+__global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
     const uint32_t n = min(io.ctr->n_shade[Q_TERMINAL], io.cap_slots_term);
-    for (uint32_t idx = block * blockDim.x + threadIdx.x; idx < n; idx += n_blocks * blockDim.x)
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
     {
         const uint2 e2 = io.entries[idx];
         const uint32_t entry = e2.x, pid = e2.y;
@@ -2779,24 +2776,11 @@ __device__ __forceinline__ void shade_terminal_body(const SceneView& sv, const R
         io.st.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f}; // every entry of this queue is a finished path
     }
 }
-__global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
-{
-    shade_terminal_body(sv, rp, io, bounce, blockIdx.x, gridDim.x);
-}
 
 // Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
 template <uint32_t QCLASS, bool VOLUMES>
-__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce,
-                                                                    const uint32_t term_blocks)
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
 {
-    // the last term_blocks workgroups of the launch are the bounce's terminal pass (launch_shade): one launch less per bounce, and its
-    // workgroups start as the surface pass's first ones retire
-    const uint32_t surface_blocks = gridDim.x - term_blocks;
-    if (blockIdx.x >= surface_blocks)
-    {
-        shade_terminal_body(sv, rp, io, bounce, blockIdx.x - surface_blocks, term_blocks);
-        return;
-    }
     __shared__ BlockAppend sh_append;
     __shared__ uint32_t sh_tail[kTailStripes];
     __shared__ uint32_t sh_extent;
@@ -2820,7 +2804,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
     // Everything this pass needs of a hit arrives in queue order (ShadeQueue): direction | path id, t u v | hit id, origin.  The first
     // word of the NEXT iteration is fetched one iteration ahead, so the path-record load that depends on its path id starts as soon
     // as an iteration begins instead of one memory round trip later.
-    const uint32_t stride = surface_blocks * blockDim.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const f4 hole_a{0.0f, 0.0f, 0.0f, asf(HOLE)};
     f4 a_next = idx < n ? nt_load(io.q_in.a + idx) : hole_a;
@@ -3519,7 +3503,7 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, wb.cap_slots, row_heads(wb, b, HEADS_LCHAIN), out);
 }
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env, bool with_terminal)
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env)
 {
     ShadeIO io{};
     io.env = env;
@@ -3547,27 +3531,25 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.ctr = wb.counters + b;
     io.lchain_heads = row_heads(wb, b, HEADS_LCHAIN);
     io.ctr_next = wb.counters + b + 1u;
-    static_assert(PT_SHADE_THREADS == 256, "the terminal pass a surface launch carries runs 256-thread workgroups");
-    const uint32_t term_blocks = (with_terminal && qclass != Q_TERMINAL) ? grid_blocks : 0u;
-    const uint32_t surface_blocks = (grid_blocks * 256u + PT_SHADE_THREADS - 1u) / PT_SHADE_THREADS + term_blocks; // grid_blocks is in units of 256 threads
+    const uint32_t surface_blocks = (grid_blocks * 256u + PT_SHADE_THREADS - 1u) / PT_SHADE_THREADS; // grid_blocks is in units of 256 threads
     switch (qclass)
     {
     case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
     case Q_LAMBERT:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
-        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_SPECULAR:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
-        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_DIELECTRIC:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
-        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     case Q_GGX:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
-        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b, term_blocks);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
         break;
     default: break;
     }

@@ -126,6 +126,9 @@ namespace {
 #define PT_CLAIM_AHEAD 0 // rays left in a chunk when the next one is claimed; 0 = as soon as the chunk is taken up (same-box A/B of 64 / 128 / 256: +0.3 ms for a 1/8 share, +3 ms per frame)
 #endif
 // threads per shading workgroup (a workgroup makes one reservation per queue and iteration: block_append4)
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 1 // waves per SIMD the surface shading kernels must leave room for (1: whatever the registers they want allow)
+#endif
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
@@ -2778,9 +2781,29 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
 }
 
 // Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
-template <uint32_t QCLASS, bool VOLUMES>
-__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneView sv, const RenderParams rp, const ShadeIO io, const uint32_t bounce)
+// The launch description as ONE kernel argument (offset 0 of the kernel-argument segment), so that a section of the kernel can read its
+// fields from there when it runs (shade_args) instead of holding them in scalar registers across the whole iteration.
+struct ShadeKArgs { SceneView sv; RenderParams rp; ShadeIO io; uint32_t bounce; };
+typedef const __attribute__((address_space(4))) ShadeKArgs* ShadeKArgsPtr;
+__device__ __forceinline__ const ShadeKArgs& shade_args()
 {
+    ShadeKArgsPtr p = (ShadeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));        // loads through p cannot move above this point
+    return *(const ShadeKArgs*)p;
+}
+#define PT_SHADE_ARGS                                                                                                              \
+    const ShadeKArgs& ka_ = shade_args();                                                                                          \
+    [[maybe_unused]] const SceneView& sv = ka_.sv;                                                                                 \
+    [[maybe_unused]] const RenderParams& rp = ka_.rp;                                                                              \
+    [[maybe_unused]] const ShadeIO& io = ka_.io;
+template <uint32_t QCLASS, bool VOLUMES>
+__global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_WAVES) k_shade_surface(const ShadeKArgs kargs)
+{
+    // Only what the loop header needs is taken from the argument here; each section of an iteration re-reads the launch description from
+    // the kernel-argument segment (PT_SHADE_ARGS: scalar loads that hit the constant cache) instead of keeping ~130 words of it in ~100
+    // scalar registers for the whole iteration: spilled scalars 81 -> 0 (every class), static VALU 1947 -> 1747 (no v_readlane / v_writelane).
+    const ShadeIO& io = kargs.io;
+    const uint32_t bounce = kargs.bounce;
     __shared__ BlockAppend sh_append;
     __shared__ uint32_t sh_tail[kTailStripes];
     __shared__ uint32_t sh_extent;
@@ -2821,6 +2844,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
         uint32_t draws = 0;
         if (valid)
         {
+            PT_SHADE_ARGS
             pid = asu(rb.w);
             const f4 hit = nt_load(io.q_in.b + idx);
             const f4 ra = bounce == 0u ? io.primary_a : nt_load(io.q_in.c + idx);
@@ -2947,6 +2971,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
             {
                 // ---- estimate_direct_explicit  integrator.rs:25-74
                 {
+                    PT_SHADE_ARGS
                     const float x = rng.f32();                                         // light_sampler.rs:33
                     // binary_search_by(total_cmp): for a non-decreasing cdf Ok(i)/Err(i) = number of entries below x
                     uint32_t li = 0, hi = sv.n_lights;
@@ -2988,6 +3013,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
                 }
                 // ---- estimate_direct_bsdf  integrator.rs:77-130
                 {
+                    PT_SHADE_ARGS
                     const f3 dir = mat_scatter(mat, rng, rd, normal, front);
                     if (dot3(dir, normal) > 0.0f)                                      // integrator.rs:96
                     {
@@ -3054,6 +3080,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
             }
         }
         // ---- block-aggregated queue appends (every thread of the block reaches this): one atomic per queue per block
+        PT_SHADE_ARGS
         uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
         const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
         const uint32_t caps[4] = {io.cap_slots, io.cap_slots, io.cap_slots, io.cap_slots_term};
@@ -3095,6 +3122,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade_surface(const SceneV
     }
     add_tally(io.lchain_heads, culled, HEAD_TALLY2);
 }
+
+#undef PT_SHADE_ARGS
 
 // integrator.rs:272-280: finite check, clamp_length_max(100), alpha 1
 __device__ __forceinline__ f3 finalise(f3 acc)
@@ -3532,24 +3561,25 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.lchain_heads = row_heads(wb, b, HEADS_LCHAIN);
     io.ctr_next = wb.counters + b + 1u;
     const uint32_t surface_blocks = (grid_blocks * 256u + PT_SHADE_THREADS - 1u) / PT_SHADE_THREADS; // grid_blocks is in units of 256 threads
+    const ShadeKArgs ka{sv, rp, io, b};
     switch (qclass)
     {
     case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
     case Q_LAMBERT:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
+        else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         break;
     case Q_SPECULAR:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
+        else hipLaunchKernelGGL((k_shade_surface<Q_SPECULAR, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         break;
     case Q_DIELECTRIC:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
+        else hipLaunchKernelGGL((k_shade_surface<Q_DIELECTRIC, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         break;
     case Q_GGX:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
-        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, sv, rp, io, b);
+        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_GGX, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
+        else hipLaunchKernelGGL((k_shade_surface<Q_GGX, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         break;
     default: break;
     }

@@ -107,7 +107,9 @@ int pt_add_model_obj(pt_ctx* ctx, const char* path, int material, const float* a
 /* triangle soup of a model as loaded (n_tris*9 floats each); pass cap_tris = 0 to query *n_tris */
 int pt_model_vertices(pt_ctx* ctx, int model, float* positions_xyz, float* normals_xyz, uint32_t cap_tris, uint32_t* n_tris);
 /* BLAS (SAH sweep, blas_bvh.rs:62-136) + world/light TLAS (agglomerative, tlas_bvh.rs:85-138) + LightSampler
- * (light_sampler.rs:41-61) on the host; flattened for the device.  No GPU is touched until the first render/trace. */
+ * (light_sampler.rs:41-61) on the host; flattened for the device.  No GPU is touched until the first render/trace.
+ * The trees are the reference's node for node; the SAH sweep of a large model forks its subtrees onto up to 16 host threads
+ * (environment PTMI_BUILD_THREADS=n overrides, 1 = the caller's thread only; PTMI_DEBUG_BUILD=1 prints stage times on stderr). */
 int pt_build(pt_ctx* ctx);
 
 /* ---- Camera::new / create_ray  src/camera.rs:17-31, 94-105 ---------------------------------------------------- */

@@ -84,6 +84,31 @@ xf34 inverse_affine(const xf34& a) // glam Affine3A::inverse
     return xf34{mi, -mul(mi, a.t)};
 }
 
+// host threads of Scene::new: the cores up to 16; PTMI_BUILD_THREADS overrides (1 = the caller's thread only)
+unsigned build_threads()
+{
+    unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    if (const char* e = std::getenv("PTMI_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(atoi(e), 64));
+    return threads;
+}
+// fn(lo, hi) over [0, n) in equal slices, one per thread (independent elements only)
+template <class F>
+void parallel_slices(size_t n, F fn)
+{
+    const size_t t = std::min<size_t>(build_threads(), n / 4096 + 1);
+    if (t <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    size_t started = 1;
+    try
+    {
+        for (; started < t; ++started) pool.emplace_back(fn, n * started / t, n * (started + 1) / t);
+    }
+    catch (const std::system_error&) {}                                                  // fewer threads than asked for: the caller does the rest
+    fn((size_t)0, n / t);
+    if (started < t) fn(n * started / t, n);
+    for (std::thread& th : pool) th.join();
+}
+
 // SAH sweep builder over a contiguous span of (box, primitive) records.  The tree is the reference's, node for node (tests/test_host.py
 // compares the arena with the oracle's direct restatement); what differs is how it is reached:
 //  * the reference folds a box over each side of every candidate split (64 x n joins per node, blas_bvh.rs:96-110).  The left boxes
@@ -450,22 +475,22 @@ void HostScene::build_blas(HostBlas& out, const HostModel& m)                   
 {
     out = HostBlas();
     out.material = m.material;
-    out.tris.reserve(m.n_tris);
+    out.tris.resize(m.n_tris);
     std::vector<SweepItem> items(m.n_tris);
-    for (uint32_t i = 0; i < m.n_tris; ++i)
-    {
-        out.tris.push_back(make_triangle(&m.positions[(size_t)i * 9], &m.normals[(size_t)i * 9]));
-        items[i] = SweepItem{triangle_box(out.tris.back()), i};
-    }
+    parallel_slices(m.n_tris, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i)
+        {
+            out.tris[i] = make_triangle(&m.positions[i * 9], &m.normals[i * 9]);
+            items[i] = SweepItem{triangle_box(out.tris[i]), (uint32_t)i};
+        }
+    });
     const auto tt0 = std::chrono::steady_clock::now();
     SweepBuilder sb{items};
     SweepArena arena;
     arena.nodes.reserve(2 * items.size());
     arena.prim_ids.reserve(items.size());
-    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);               // PTMI_BUILD_THREADS overrides (1 = build in the caller's thread)
-    if (const char* e = std::getenv("PTMI_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(atoi(e), 64));
     int fork_levels = 0;                                                                 // 2^levels builder threads
-    for (unsigned t = threads; t > 1; t >>= 1) ++fork_levels;
+    for (unsigned t = build_threads(); t > 1; t >>= 1) ++fork_levels;
     out.root = sb.run(arena, 0, items.size(), 4, &out.depth, fork_levels);               // last_split_axis = 4  blas.rs:191
     out.nodes.assign(arena.nodes.begin(), arena.nodes.end());                            // exact size; the arena was reserved for the worst case
     out.prim_ids = std::move(arena.prim_ids);
@@ -691,14 +716,22 @@ int HostScene::flatten(std::string* err)
             if (bl.nodes[n].kind == NODE_BRANCH) { d.link = (NODE_BRANCH << NODE_KIND_SHIFT) | slot_of[bl.nodes[n].a]; d.aux = slot_of[bl.nodes[n].b]; }
             else { d.link = leaf_link(f.tri_base[i] + bl.nodes[n].a, bl.nodes[n].b); d.aux = bl.nodes[n].b; }
         }
-        for (uint32_t id : bl.prim_ids) // triangles stored in leaf order
-        {
-            const HostTriangle& t = bl.tris[id];
-            f.tri_isect.push_back(DTriIsect{t.n0, t.n1, t.n2});
-            f.tri_shade.push_back(DTriVerts{f4{t.n[0].x, t.n[0].y, t.n[0].z, 0}, f4{t.n[1].x, t.n[1].y, t.n[1].z, 0}, f4{t.n[2].x, t.n[2].y, t.n[2].z, 0}});
-            f.tri_pos.push_back(DTriVerts{f4{t.p[0].x, t.p[0].y, t.p[0].z, 0}, f4{t.p[1].x, t.p[1].y, t.p[1].z, 0}, f4{t.p[2].x, t.p[2].y, t.p[2].z, 0}});
-            f.tri_orig.push_back(id);
-        }
+        const size_t at = f.tri_orig.size(); // triangles stored in leaf order
+        f.tri_isect.resize(at + bl.prim_ids.size());
+        f.tri_shade.resize(at + bl.prim_ids.size());
+        f.tri_pos.resize(at + bl.prim_ids.size());
+        f.tri_orig.resize(at + bl.prim_ids.size());
+        parallel_slices(bl.prim_ids.size(), [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k)
+            {
+                const uint32_t id = bl.prim_ids[k];
+                const HostTriangle& t = bl.tris[id];
+                f.tri_isect[at + k] = DTriIsect{t.n0, t.n1, t.n2};
+                f.tri_shade[at + k] = DTriVerts{f4{t.n[0].x, t.n[0].y, t.n[0].z, 0}, f4{t.n[1].x, t.n[1].y, t.n[1].z, 0}, f4{t.n[2].x, t.n[2].y, t.n[2].z, 0}};
+                f.tri_pos[at + k] = DTriVerts{f4{t.p[0].x, t.p[0].y, t.p[0].z, 0}, f4{t.p[1].x, t.p[1].y, t.p[1].z, 0}, f4{t.p[2].x, t.p[2].y, t.p[2].z, 0}};
+                f.tri_orig[at + k] = id;
+            }
+        });
     }
     auto put_instances = [&](const HostTlas& t) {
         for (const HostInstance& hi : t.instances)

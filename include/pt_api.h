@@ -109,7 +109,9 @@ int pt_model_vertices(pt_ctx* ctx, int model, float* positions_xyz, float* norma
 /* BLAS (SAH sweep, blas_bvh.rs:62-136) + world/light TLAS (agglomerative, tlas_bvh.rs:85-138) + LightSampler
  * (light_sampler.rs:41-61) on the host; flattened for the device.  No GPU is touched until the first render/trace.
  * The trees are the reference's node for node; the SAH sweep of a large model forks its subtrees onto up to 16 host threads
- * (environment PTMI_BUILD_THREADS=n overrides, 1 = the caller's thread only; PTMI_DEBUG_BUILD=1 prints stage times on stderr). */
+ * (environment PTMI_BUILD_THREADS=n overrides, 1 = the caller's thread only; PTMI_DEBUG_BUILD=1 prints stage times on stderr).
+ * PT_ERR_LIMIT: the scene exceeds a packing limit, or the host ran out of memory building it (pt_add_model* likewise): no C++
+ * exception crosses this boundary. */
 int pt_build(pt_ctx* ctx);
 
 /* ---- Camera::new / create_ray  src/camera.rs:17-31, 94-105 ---------------------------------------------------- */

@@ -1116,7 +1116,9 @@ int pt_add_model(pt_ctx* c, const float* positions, const float* normals, uint32
 {
     if (!c) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    int r = c->scene.add_model(positions, normals, n_tris, material, affines, n_inst);
+    int r;
+    try { r = c->scene.add_model(positions, normals, n_tris, material, affines, n_inst); }
+    catch (const std::exception& e) { return fail(c, PT_ERR_LIMIT, std::string("model does not fit in host memory: ") + e.what()); }
     if (r == -4) return fail(c, PT_ERR_NONRIGID, "Model matrix can only contain translation and rotation");
     if (r < 0) return fail(c, PT_ERR_ARG, "bad model description");
     c->scene_uploaded = false;
@@ -1128,7 +1130,9 @@ int pt_add_model_obj(pt_ctx* c, const char* path, int material, const float* aff
     if (!c || !path) return PT_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     std::string err;
-    int r = c->scene.add_model_obj(path, material, affines, n_inst, &err);
+    int r;
+    try { r = c->scene.add_model_obj(path, material, affines, n_inst, &err); }
+    catch (const std::exception& e) { return fail(c, PT_ERR_LIMIT, std::string("model does not fit in host memory: ") + e.what()); }
     if (r == -4) return fail(c, PT_ERR_NONRIGID, "Model matrix can only contain translation and rotation");
     if (r == -6) return fail(c, PT_ERR_IO, err);
     if (r == -7) return fail(c, PT_ERR_PARSE, err);
@@ -1157,7 +1161,10 @@ int pt_build(pt_ctx* c)
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->scene.materials.size() > 255) return fail(c, PT_ERR_LIMIT, "at most 255 materials (volume stacks hold 8-bit material indices)");
     std::string err;
-    int r = c->scene.build(&err);
+    int r;
+    // the host builders allocate (and fork threads): a failed allocation is an error code for the caller, not an exception through a C ABI
+    try { r = c->scene.build(&err); }
+    catch (const std::exception& e) { c->scene.built = false; return fail(c, PT_ERR_LIMIT, std::string("scene build failed on the host: ") + e.what()); }
     c->scene_uploaded = false;
     c->scene_version++;
     if (r) return fail(c, r == -5 ? PT_ERR_LIMIT : PT_ERR_STATE, err);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <numeric>
 #include <system_error>
 #include <thread>
@@ -98,15 +99,26 @@ void parallel_slices(size_t n, F fn)
     const size_t t = std::min<size_t>(build_threads(), n / 4096 + 1);
     if (t <= 1) { fn((size_t)0, n); return; }
     std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(t);
     size_t started = 1;
     try
     {
-        for (; started < t; ++started) pool.emplace_back(fn, n * started / t, n * (started + 1) / t);
+        for (; started < t; ++started)
+            pool.emplace_back([&fn, &failed, started, n, t] {
+                try { fn(n * started / t, n * (started + 1) / t); }
+                catch (...) { failed[started] = std::current_exception(); }              // handed to the caller after the join
+            });
     }
     catch (const std::system_error&) {}                                                  // fewer threads than asked for: the caller does the rest
-    fn((size_t)0, n / t);
-    if (started < t) fn(n * started / t, n);
+    try
+    {
+        fn((size_t)0, n / t);
+        if (started < t) fn(n * started / t, n);
+    }
+    catch (...) { failed[0] = std::current_exception(); }
     for (std::thread& th : pool) th.join();
+    for (const std::exception_ptr& e : failed)
+        if (e) std::rethrow_exception(e);
 }
 
 // SAH sweep builder over a contiguous span of (box, primitive) records.  The tree is the reference's, node for node (tests/test_host.py
@@ -231,11 +243,16 @@ struct SweepBuilder
             {
                 la.nodes.reserve(2 * best_j); la.prim_ids.reserve(best_j);
                 ra.nodes.reserve(2 * (span - best_j)); ra.prim_ids.reserve(span - best_j);
-                std::thread t([&] { left = run(la, lo, lo + best_j, axis, &dl, fork_levels - 1); });
+                std::exception_ptr left_failed;
+                std::thread t([&] {
+                    try { left = run(la, lo, lo + best_j, axis, &dl, fork_levels - 1); }
+                    catch (...) { left_failed = std::current_exception(); }              // e.g. bad_alloc: rethrown in the parent after the join
+                });
                 forked = true;
                 try { right = run(ra, lo + best_j, hi, axis, &dr, fork_levels - 1); }
                 catch (...) { t.join(); throw; }
                 t.join();
+                if (left_failed) std::rethrow_exception(left_failed);
             }
             catch (const std::system_error&) {}                                          // no thread to be had: build the children in turn
             if (forked)

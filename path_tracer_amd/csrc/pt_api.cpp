@@ -272,20 +272,16 @@ int upload_scene(pt_ctx* c)
     sv.blob_bytes = (uint32_t)blob.size();
     sv.stack_entries = f.stack_entries;
     sv.has_volumes = f.has_volumes ? 1u : 0u;
-    sv.trav_flags = f.trav_flags;
 
     // launch geometry of the traversal kernels: BVH in LDS when it is small, per-lane stacks always in LDS
     c->lds_scene = blob.size() <= 48 * 1024 && !(c->cfg.flags & PT_FLAG_NO_LDS_SCENE);
-    // small LDS scenes: eight direction-octant copies of the node array, so that the box test needs no per-axis select (stage_scene)
-    const size_t oct_bytes = blob.size() + 7 * nb;
-    if (PT_OCT_NODES && c->lds_scene && oct_bytes <= PT_OCT_MAX_BYTES) sv.trav_flags |= TRAV_OCT_NODES;
-    const size_t blob_lds = c->lds_scene ? ((sv.trav_flags & TRAV_OCT_NODES) ? oct_bytes : blob.size()) : 0;
     uint32_t threads = 256;
 #ifndef PT_STACK_LDS_LEVELS
 #define PT_STACK_LDS_LEVELS 14
 #endif
     sv.stack_lds = std::min<uint32_t>(sv.stack_entries, c->cfg.stack_lds_levels ? c->cfg.stack_lds_levels : PT_STACK_LDS_LEVELS); // deeper levels spill to global memory
-    auto lds_need = [&](uint32_t t) { return blob_lds + (size_t)sv.stack_lds * t * 8 + (size_t)PT_CAND_SLOTS * t * 16; }; // + k_closest2's per-lane FIFO
+    // (the same helper the launchers size their dynamic LDS with: the budget check and the launch cannot disagree)
+    auto lds_need = [&](uint32_t t) { return trace_lds_bytes(c->lds_scene, sv.blob_bytes, sv.stack_lds, t); };
     while (threads > 64 && lds_need(threads) > 64 * 1024) threads >>= 1;
     if (lds_need(threads) > 160 * 1024) return fail(c, PT_ERR_LIMIT, "BVH too deep for the LDS traversal stack");
     c->block_threads = threads;
@@ -2147,7 +2143,7 @@ int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint
         return PT_OK;
     }
 #endif
-    // PTMI_STEP_STATS_BASE=16: the second group of eight words (PT_STEP_STATS=2 builds: section times)
+    // PTMI_STEP_STATS_BASE=16: a second group of eight words, for instrumented builds that fill it
     const char* base_env = std::getenv("PTMI_STEP_STATS_BASE");
     const uint32_t base = base_env && std::atoi(base_env) == 16 ? 16u : 8u;
     // PTMI_STEP_STATS_QUEUE=shadow: the shadow-ray launches' statistics (k_any) instead of the closest-hit launches'

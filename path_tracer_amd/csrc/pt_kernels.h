@@ -17,6 +17,13 @@ struct TraceLaunch
     uint32_t block_threads;  // 64..256
 };
 
+// dynamic LDS of a traversal workgroup: the staged BVH blob (LDS scenes) + the per-lane (node, t_enter) stacks
+inline size_t trace_lds_bytes(bool lds_scene, uint32_t blob_bytes, uint32_t stack_lds, uint32_t block_threads)
+{
+    return (lds_scene ? (size_t)blob_bytes : 0) + (size_t)stack_lds * block_threads * 8;
+}
+inline size_t trace_lds_bytes(const TraceLaunch& tl) { return trace_lds_bytes(tl.lds_scene, tl.scene.blob_bytes, tl.scene.stack_lds, tl.block_threads); }
+
 struct WavefrontBuffers
 {
     PathState st;

@@ -63,32 +63,9 @@ namespace {
 #ifndef PT_BRANCH_LEVELS_ANY
 #define PT_BRANCH_LEVELS_ANY 4
 #endif
-// closest-hit traversal with deferred leaves (k_closest2) for the world / primary / hook launches; 0 = the round-2 kernel everywhere
-#ifndef PT_TWO_PHASE
-#define PT_TWO_PHASE 0
-#endif
-#ifndef PT_SORT_RETIRE
-#define PT_SORT_RETIRE 0
-#endif
-#if PT_TWO_PHASE != 0 && PT_OCT_NODES
-#error "k_closest2 / k_closest3 stage the plain BVH blob: build PT_TWO_PHASE variants with -DPT_OCT_NODES=0"
-#endif
 // frames with fewer local pixels than this use four lanes per pixel in k_accumulate (k_accumulate<FEW_PIXELS>)
 #ifndef PT_ACC_QUAD_BELOW
 #define PT_ACC_QUAD_BELOW (1u << 30) // (whole 1080p frame: 0.675 -> 0.55 ms; beyond 2^30 pixels the thread index would overflow)
-#endif
-// k_any with streamed lanes (a next-ray register set per lane, set-up in batches; any_body).  An experiment, off: bit-exact (82 GPU tests),
-// same-box A/B per 256-spp Cornell frame: 68.5-68.8 ms without; looks at the buffers every 1 / 2 / 3 wave-steps 73.4 / 71.7 / 74.4 ms,
-// every 4 steps 68.6-68.9 ms (set-up batches at 32 or 48 empty lanes alike).  Shadow rays are short: what the fuller lanes return, the
-// looks at the buffers and the register moves of a hand-over cost again.
-#ifndef PT_ANY_STREAM
-#define PT_ANY_STREAM 0
-#endif
-#ifndef PT_ANY_STREAM_IN
-#define PT_ANY_STREAM_IN 32
-#endif
-#ifndef PT_ANY_STREAM_STEPS
-#define PT_ANY_STREAM_STEPS 4
 #endif
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
@@ -306,29 +283,6 @@ __device__ __forceinline__ uint32_t claim_rays(WaveRange& wr, uint32_t* heads, c
     // launch's tail is that much shorter.
     if (PT_CLAIM_AHEAD != 0 && !wr.nx_valid && !wr.drained && wr.end - wr.cur <= (uint32_t)PT_CLAIM_AHEAD) prefetch_claim(wr, heads, pl);
     return take;
-}
-
-// Which queue slot the k-th ray handed out is: slot k, unless PT_SHUFFLE_BITS deals the slots of every full block of 2^PT_SHUFFLE_BITS
-// rays in bit-reversed order (BVH in global memory only), so that the 64 lanes of a wave hold rays from all over the block instead of 64
-// neighbours.  An experiment, off by default.  Through the C-ABI hook (tools/sort_probe.py: rays leaving the camera rays' first hits on
-// the 82 k-triangle mesh in uniformly random directions) queue order took 480 us, sorted by direction octant x origin cell 467, 64- or
-// 1024-ray groups shuffled 440-445, every ray shuffled 340 us — mixing the rays INSIDE a wave paid, sorting them did not.  In the renderer
-// itself it does not: same-box A/B with 2^12 / 2^16 / 2^20-ray blocks on every launch: 82 k mesh 14.15 -> 14.4-14.5 ms, three spheres
-// 10.4 -> 10.8-11.1 ms (coherent camera rays and short shadow rays lose); on the world launches of bounces >= 1 only: 8.8 -> 8.8 ms of
-// closest-hit time on the 82 k mesh, 16.7-17.0 -> 16.7-16.9 ms on the 328 k mesh.  The bounce rays of a real frame are already mixed.
-#ifndef PT_SHUFFLE_BITS
-#define PT_SHUFFLE_BITS 0
-#endif
-#ifndef PT_SHUFFLE_WORLD_ONLY
-#define PT_SHUFFLE_WORLD_ONLY 1
-#endif
-template <bool LDS_SCENE, bool ENABLE = true>
-__device__ __forceinline__ uint32_t fetch_slot(uint32_t k, uint32_t n)
-{
-    if (LDS_SCENE || !ENABLE || PT_SHUFFLE_BITS == 0) return k;
-    const uint32_t block = k & ~((1u << PT_SHUFFLE_BITS) - 1u);
-    if (block + (1u << PT_SHUFFLE_BITS) > n) return k; // the queue's last, partial block stays in order
-    return block | (__brev(k) >> ((32 - PT_SHUFFLE_BITS) & 31));
 }
 
 // exact count of what a wave processed, added to the cursor line of its home partition (64 addresses per queue instead of one)
@@ -595,7 +549,6 @@ struct Blob
     const uint4* tris;  // 3 words per triangle
     const uint4* inst;  // 7 words per instance
     const uint2* leaves; // big-leaf table {first, count} (NODE_TRIS_BIG)
-    uint32_t oct_stride; // octant copies of the node array (stage_scene<.., true>): 16-byte words from one copy to the next, else 0
 };
 // triangles of a leaf link
 __device__ __forceinline__ void leaf_range(const Blob& bl, uint32_t kind, uint32_t payload, uint32_t& first, uint32_t& count)
@@ -645,80 +598,24 @@ __device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, cons
     return r;
 }
 
-// OCT (small LDS-resident BVHs, TRAV_OCT_NODES; an experiment, -DPT_OCT_NODES=1): the node array is written to LDS EIGHT times, copy k
-// holding every box as {the corner a ray of direction octant k reaches first | link, the opposite corner | aux} (k bit 0/1/2:
-// inv.x/y/z < 0).  The box test then needs no per-axis select of the nearer plane (slab_sorted: 11 VALU instructions instead of 17 — 12
-// of the ~50 a branch level costs), with the same operands in the same operations, so the same bits (all 82 GPU tests pass).  It is
-// SLOWER: Cornell 68.6 -> 76.1 ms per frame (closest-hit launches +17 %).  The 64 lanes of a wave expand at most 23 distinct child pairs
-// of this 46-node tree, so most of their four 16-byte LDS reads per level are the same address and are broadcast; with eight copies
-// the lanes of different octants read different addresses, a level becomes ~4 KB of LDS traffic per wave, and LDS bandwidth
-// (128 B per clock and CU, shared by 16 waves) binds before VALU issue does.  What the box test saves in instructions it pays in LDS time.
-template <bool LDS_SCENE, bool OCT = false>
+template <bool LDS_SCENE>
 __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __restrict__ gblob, uint4* smem, uint32_t& words)
 {
     Blob b;
-    b.oct_stride = 0u;
+    const uint4* base = gblob;
+    words = 0;
     if (LDS_SCENE)
     {
-        const uint32_t plain = sv.blob_bytes >> 4, node_words = 2u * sv.n_nodes;
-        uint4* rest = smem;
-        if (OCT)
-        {
-            for (uint32_t i = threadIdx.x; i < sv.n_nodes; i += blockDim.x)
-            {
-                const uint4 w0 = gblob[2u * i], w1 = gblob[2u * i + 1u];
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k)
-                {
-                    const bool nx = (k & 1u) != 0u, ny = (k & 2u) != 0u, nz = (k & 4u) != 0u;
-                    smem[k * node_words + 2u * i] = make_uint4(nx ? w1.x : w0.x, ny ? w1.y : w0.y, nz ? w1.z : w0.z, w0.w);
-                    smem[k * node_words + 2u * i + 1u] = make_uint4(nx ? w0.x : w1.x, ny ? w0.y : w1.y, nz ? w0.z : w1.z, w1.w);
-                }
-            }
-            rest = smem + 7u * node_words; // so that rest[i] is word i of the plain layout for i >= node_words
-            for (uint32_t i = node_words + threadIdx.x; i < plain; i += blockDim.x) rest[i] = gblob[i];
-            words = plain + 7u * node_words;
-            b.oct_stride = node_words;
-        }
-        else
-        {
-            words = plain;
-            for (uint32_t i = threadIdx.x; i < plain; i += blockDim.x) smem[i] = gblob[i];
-        }
+        words = sv.blob_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) smem[i] = gblob[i];
         __syncthreads();
-        b.nodes = smem;
-        b.tris = rest + 2u * sv.n_nodes;
-        b.inst = rest + 2u * sv.n_nodes + 3u * sv.n_tris;
-        b.leaves = reinterpret_cast<const uint2*>(rest + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
+        base = smem;
     }
-    else
-    {
-        words = 0;
-        b.nodes = gblob;
-        b.tris = gblob + 2u * sv.n_nodes;
-        b.inst = gblob + 2u * sv.n_nodes + 3u * sv.n_tris;
-        b.leaves = reinterpret_cast<const uint2*>(gblob + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
-    }
+    b.nodes = base;
+    b.tris = base + 2u * sv.n_nodes;
+    b.inst = base + 2u * sv.n_nodes + 3u * sv.n_tris;
+    b.leaves = reinterpret_cast<const uint2*>(base + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
     return b;
-}
-// which copy a ray reads (the predicates of slab(): inv < 0 picks the max plane as the nearer one)
-__device__ __forceinline__ uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u); }
-// slab() on a box stored as (nearer corner, farther corner) for this ray's octant
-__device__ __forceinline__ bool slab_sorted(const uint4 wn, const uint4 wf, const f3 o, const f3 inv, const float t_max, float& t_enter)
-{
-    typedef float pair_t __attribute__((ext_vector_type(2)));
-    const pair_t px = (pair_t{asf(wn.x), asf(wf.x)} - pair_t{o.x, o.x}) * pair_t{inv.x, inv.x};
-    const pair_t py = (pair_t{asf(wn.y), asf(wf.y)} - pair_t{o.y, o.y}) * pair_t{inv.y, inv.y};
-    const pair_t pz = (pair_t{asf(wn.z), asf(wf.z)} - pair_t{o.z, o.z}) * pair_t{inv.z, inv.z};
-    const float ts = fmaxf(fmaxf(fmaxf(px.x, py.x), pz.x), PT_EPSILON);
-    const float tb = fminf(fminf(fminf(px.y, py.y), pz.y), t_max);
-    t_enter = ts;
-    return ts <= tb;
-}
-template <bool OCT>
-__device__ __forceinline__ bool slab_n(const uint4 w0, const uint4 w1, const f3 o, const f3 inv, const float t_max, float& t_enter)
-{
-    return OCT ? slab_sorted(w0, w1, o, inv, t_max, t_enter) : slab(w0, w1, o, inv, t_max, t_enter);
 }
 
 // CLOSEST_PRIMARY = CLOSEST_WORLD for bounce 0: every ray starts at the eye (only directions are stored, ray index == path id)
@@ -833,7 +730,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                                              const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
                                              uint32_t* __restrict__ heads, const ClosestOutPtr outp)
 {
-    constexpr bool LDS_SCENE = BVH != 0, OCT = BVH == 2; // BVH: 0 in global memory, 1 in LDS, 2 in LDS with octant copies of the nodes (stage_scene)
+    constexpr bool LDS_SCENE = BVH != 0; // BVH: 0 in global memory, 1 in LDS
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
     if (blockIdx.x >= plan.blocks) return; // a short queue keeps only as many workgroups as it has 64-ray chunks
     // per-lane stack of (node, t_enter), [level][thread] in LDS (conflict-free ds_read_b64 / ds_write_b64)
@@ -843,7 +740,6 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
     bool active = false, pending = false, ray_finite = false;
     uint32_t ray_idx = 0, pid = 0;
     LaneRay w{}, ob{};
-    uint32_t nb_w = 0, nb_o = 0; // OCT: word offsets of the node copies of the world-space / object-space ray's direction octant
     float t_max = 0.0f, bt = 0.0f;
     float hud = 0.0f, hvd = 0.0f, hdet = 1.0f; // best hit's (u, v) numerators and determinant: divided once, when the ray retires (primitive.rs:158-160)
     uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0;
@@ -1019,7 +915,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
-                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0 || MODE == CLOSEST_WORLD>(first + rank, plan.n);
+                const uint32_t mine = first + rank;
                 const f4 b = rb[mine];
                 ray_idx = mine;
                 pid = asu(b.w);
@@ -1038,7 +934,6 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 }
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
-                if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
                 ray_finite = finite3(w.o) && finite3(w.d);
                 bid = MISS_ID;
                 any_phase = false;
@@ -1051,8 +946,8 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 sp = stk.empty();
                 // TLAS::intersect: root box test, then (root, 0.0)   tlas.rs:68-74
                 float te;
-                const uint4 root0 = bl.nodes[nb_w + 2u * root];
-                const bool ok = (t_max == t_max) && slab_n<OCT>(root0, bl.nodes[nb_w + 2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[2u * root];
+                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
                     stk.put(sp, make_uint2(root0.w, 0u));    // entries are (link, t_enter); the root goes in with t_enter 0
@@ -1095,22 +990,21 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 {
                     uint32_t blas_root;
                     ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
-                    if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                     in_blas = true;
                     blas_base = sp;
-                    const uint4 r0 = bl.nodes[nb_o + 2u * blas_root];
-                    if (!slab_n<OCT>(r0, bl.nodes[nb_o + 2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                    const uint4 r0 = bl.nodes[2u * blas_root];
+                    if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
                     link = r0.w;
                 }
                 const uint32_t kkind = link >> NODE_KIND_SHIFT, kpay = link & NODE_PAYLOAD_MASK;
                 if (kkind == NODE_BRANCH)
                 {
-                    const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * kpay;
+                    const uint4* cp = bl.nodes + 2u * kpay;
                     const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                     const f3 so = in_blas ? ob.o : w.o, sinv = in_blas ? ob.inv : w.inv;
                     float tl, tr;
-                    const bool hl = slab_n<OCT>(l0, l1, so, sinv, t_max, tl);
-                    const bool hr = slab_n<OCT>(r0, r1, so, sinv, t_max, tr);
+                    const bool hl = slab(l0, l1, so, sinv, t_max, tl);
+                    const bool hr = slab(r0, r1, so, sinv, t_max, tr);
                     if (hl) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }
                     if (hr) { stk.put(sp, make_uint2(r0.w, asu(tr))); sp = stk.up(sp); }
                 }
@@ -1143,9 +1037,9 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                     in_blas = false;
                     t_max = bt * (1.0f - PT_EPSILON);
                     float te = 0.0f;
-                    const uint4 wr0 = bl.nodes[nb_w + 2u * lights_world_root];
+                    const uint4 wr0 = bl.nodes[2u * lights_world_root];
                     // NaN t_max: every box test fails -> visible; so does a ray that misses the world's root box (tlas.rs:118-121)
-                    if (t_max == t_max && slab_n<OCT>(wr0, bl.nodes[nb_w + 2u * lights_world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
+                    if (t_max == t_max && slab(wr0, bl.nodes[2u * lights_world_root + 1u], w.o, w.inv, t_max, te)) { stk.put(sp, make_uint2(wr0.w, asu(te))); sp = stk.up(sp); }
                     else { active = false; pending = true; chain_code = 0u; }
                     continue;
                 }
@@ -1168,7 +1062,6 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 uint32_t blas_root;
                 inst = link & NODE_PAYLOAD_MASK;
                 ob = to_object(bl, inst, w, ray_finite, blas_root);
-                if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                 in_blas = true;
                 blas_base = sp;
                 if (0.0f > t_max) continue;                  // the root's pop test  blas.rs:222-225
@@ -1186,12 +1079,12 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
 #pragma unroll 1
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS && kind == NODE_BRANCH; ++lvl)
             {
-                const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * payload; // the children are one contiguous 64-byte record pair
+                const uint4* cp = bl.nodes + 2u * payload; // the children are one contiguous 64-byte record pair
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
-                const bool hl = slab_n<OCT>(l0, l1, o, inv, t_max, tl);
-                const bool hr = slab_n<OCT>(r0, r1, o, inv, t_max, tr);
+                const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab(r0, r1, o, inv, t_max, tr);
                 // both hit: the farther child goes underneath (ties: left underneath, right popped first); one hit: that child
                 const bool left_near = tl < tr;
                 const uint2 le = make_uint2(l0.w, asu(tl)), re = make_uint2(r0.w, asu(tr));
@@ -1300,925 +1193,9 @@ __global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH : PT_WAVES_GL
     // (workgroups the queue has no 64-ray chunk for leave before staging anything)
     if (blockIdx.x >= fetch_plan(min(*a.n_ptr, a.cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER).blocks) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(a.sv, a.gblob, smem, blob_words);
+    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
     const ClosestOutPtr outp = &((ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr())->out;
     closest_body<BVH, MODE, SPILL>(a.sv, bl, blob_words, smem, a.root, a.ra, a.rb, a.n_ptr, a.cap_in, a.heads, outp);
-}
-
-// ------------------------------------------------------------------------------------------------ closest hit, leaves deferred
-// The reference's traversal (tlas.rs:66-110, blas.rs:214-256) interleaves two kinds of work — expand a branch, test a leaf's triangles —
-// and a wave that runs it lane by lane pays for both kinds in every step, each with a handful of lanes (profiles/r02_step_stats_cornell.md:
-// 23 of 64 lanes per VALU instruction).  What ties the two together is t_max: a hit found in a leaf prunes the boxes visited after it.
-// But the reference uses t_max in exactly two ways, and both can be postponed:
-//   * AABB::intersect_t(r, t_max) (boundingbox.rs:115-131) is  t_small <= min(t_far, t_max)  =  (t_small <= t_far) && (t_small <= t_max):
-//     a part that does not depend on t_max and a comparison of the entry distance with it.  An entry is pushed with its t_small and popped
-//     later under the test t_enter > t_max (tlas.rs:80-83, blas.rs:222-225) against a t_max that can only have shrunk in between, so the pop
-//     test subsumes the push-time comparison: a node is processed iff its box is met at all and t_enter <= t_max WHEN IT IS POPPED;
-//   * the order of the two children (blas.rs:139-153) compares their entry distances only.
-//   Box entry distances never decrease from a node to its children (a child's box lies inside its parent's, the subtraction and the
-//   multiplication by inv are monotone, NaN planes drop out on both sides; the host checks the nesting, FlatScene::nested_boxes), so a
-//   leaf that passes its own pop test has ancestors (inside its BLAS; and, for a TLAS leaf, inside the TLAS) that passed theirs.
-// So:  PHASE 1 (branch steps) walks the tree in the reference's order — nearer child first — pruning with whatever t_max the lane knows
-// (never smaller than the reference's at that moment: conservative), and instead of testing a leaf it APPENDS it to a per-lane FIFO:
-// {leaf link, entry distance of its box, instance, entry distance of the instance's TLAS box}.  PHASE 2 (leaf rounds) takes the FIFO's entries
-// in order, repeats the two pop tests the reference would have made with the t_max it would have had — the TLAS leaf's when the first
-// leaf of an instance comes up (nothing can change t_max between the instance's pop and its first leaf), then the leaf's own — and tests
-// the triangles (primitive.rs:117-178) exactly as before.  Every wave-step is ONE kind of work; which kind is put to the vote: a leaf round
-// when enough lanes hold a candidate (or nobody can expand a branch), else a branch step.
-// Instances that are not the identity (IDENT = false) keep one object-space ray per lane, so a lane enters the next instance only
-// when its FIFO is empty (it "parks" until the next leaf round).  Scenes whose instances are all the identity (every Cornell configuration)
-// compute the object-space image of the ray once, at refill.
-#ifndef PT_LEAF_VOTE
-#define PT_LEAF_VOTE 24   // lanes holding a candidate that make the next wave-step a leaf round
-#endif
-#ifndef PT_BRANCH_LEVELS2
-#define PT_BRANCH_LEVELS2 2
-#endif
-struct CandRing
-{
-    char* base;
-    uint32_t mine, step; // byte offset of this lane's slot 0; bytes per slot row (16 * blockDim.x)
-    __device__ __forceinline__ static CandRing make(uint4* smem, uint32_t blob_words, const SceneView& sv)
-    {
-        return CandRing{reinterpret_cast<char*>(smem), blob_words * 16u + sv.stack_lds * blockDim.x * 8u + threadIdx.x * 16u, blockDim.x * 16u};
-    }
-    __device__ __forceinline__ uint4 get(uint32_t i) const { return *reinterpret_cast<const uint4*>(base + mine + (i & (uint32_t)(PT_CAND_SLOTS - 1)) * step); }
-    __device__ __forceinline__ void put(uint32_t i, uint4 v) const { *reinterpret_cast<uint4*>(base + mine + (i & (uint32_t)(PT_CAND_SLOTS - 1)) * step) = v; }
-};
-
-template <bool LDS_SCENE, int MODE, bool SPILL, bool IDENT>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest2(const SceneView sv, const uint4* __restrict__ gblob, const uint32_t root, const f4* __restrict__ ra,
-                                                  const f4* __restrict__ rb, const uint32_t* __restrict__ n_ptr, const uint32_t cap_in,
-                                                  uint32_t* __restrict__ heads, const ClosestOut out)
-{
-    static_assert(MODE != CLOSEST_LIGHTS, "the fused NEE chain stays on k_closest");
-    extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
-    if (blockIdx.x >= plan.blocks) return;
-    uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
-    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv);
-    const CandRing ring = CandRing::make(smem, blob_words, sv);
-    const uint32_t prim_bits = sv.prim_bits;
-
-    bool active = false, pending = false, ray_finite = false, in_blas = false, parked = false, r_pruned = false;
-    uint32_t ray_idx = 0, pid = 0;
-    LaneRay w{}, ob{};
-    float t_max = 0.0f, bt = 0.0f, ts_inst = 0.0f;
-    float hud = 0.0f, hvd = 0.0f, hdet = 1.0f;
-    uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0, r_inst = MISS_ID;
-    uint32_t head = 0, tail = 0; // FIFO read / write positions (mod PT_CAND_SLOTS)
-    WaveRange wr = first_range(plan, heads);
-    uint32_t valid_rays = 0;
-#if PT_STEP_STATS
-    uint32_t st_iter = 0, st_lane_active = 0, st_lane_branch = 0, st_lane_leaf = 0, st_lane_test = 0, st_wave_branch = 0, st_wave_leaf = 0, st_lane_park = 0;
-#endif
-#if PT_STEP_STATS == 2
-    // wave time by section (s_memtime ticks / 64): service, branch steps, leaf rounds; and the number of services
-    uint64_t tt_service = 0, tt_branch = 0, tt_leaf = 0, tt_mark = 0;
-    uint32_t n_service = 0;
-    const uint64_t tt_start = __builtin_readcyclecounter();
-#define PT_TT_BEGIN() tt_mark = __builtin_readcyclecounter()
-#define PT_TT_END(acc) acc += __builtin_readcyclecounter() - tt_mark
-#else
-#define PT_TT_BEGIN()
-#define PT_TT_END(acc)
-#endif
-    Region bin_region[Q_COUNT];
-#pragma unroll
-    for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
-    const uint32_t rsize = out.finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
-    const Stripes stripes = stripes_for(plan.n);
-    uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    for (;;)
-    {
-        uint64_t act = __ballot(active);
-        const bool no_more = wr.drained && wr.cur >= wr.end;
-        const bool service = no_more ? (act == 0ull) : (__popcll(act) <= Refill<LDS_SCENE>::kBelow);
-        if (service)
-        {
-            PT_TT_BEGIN();
-#if PT_STEP_STATS == 2
-            n_service += 1u;
-#endif
-            // ---- retire finished lanes (as k_closest)
-            const uint64_t pm = __ballot(pending);
-            if (pm != 0ull)
-            {
-                if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
-                {
-                    uint64_t qm = pm;
-                    if (MODE == CLOSEST_PRIMARY)
-                    {
-                        const bool missed = pending && bid == MISS_ID && out.finalize_miss != 0u;
-                        if (pending) out.occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
-                        if (pending && bid == MISS_ID)
-                        {
-                            // defaults of integrator.rs:156-157 (with an environment map the terminal pass shades the miss)
-                            if (ray_idx >= out.keep_id_from) out.first_id[ray_idx - out.keep_id_from] = 255u;
-                            if (ray_idx >= out.keep_pos_from)
-                            {
-                                const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out.first_pos[ray_idx - out.keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
-                            }
-                        }
-                        qm = __ballot(pending && !missed);
-                        pending = pending && !missed;
-                    }
-                    if (MODE == CLOSEST_WORLD)
-                    {
-                        // paths that end at this hit or miss are finished here (integrator.rs:207-214, 263-266): see k_closest
-                        bool ends = false, emissive = false;
-                        uint32_t mat_id = 0;
-                        if (pending)
-                        {
-                            if (bid == MISS_ID) ends = out.finalize_miss != 0u;
-                            else
-                            {
-                                const uint4 meta = bl.inst[7u * (bid >> prim_bits) + 6u];
-                                emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
-                                mat_id = meta.z;
-                            }
-                        }
-                        if (ends)
-                        {
-                            const DPathRec& rec = out.rec[pid];
-                            const f4 acc4 = rec.acc;
-                            const uint32_t flags = asu(acc4.w);
-                            if (!(flags & FLAG_BSDF_CAST))
-                            {
-                                f3 acc = xyz(acc4);
-                                if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
-                                const f3 pw = xyz(rec.pw);
-                                if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
-                                else if (!out.enable_nee || (flags & FLAG_LAST_DELTA))
-                                {
-                                    const DMaterial& m = sv.materials[mat_id];
-                                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
-                                }
-                                out.radiance[pid] = f4{acc.x, acc.y, acc.z, 0.0f};
-                                pending = false;
-                            }
-                        }
-                        qm = __ballot(pending);
-                    }
-                    if (qm != 0ull)
-                    {
-                        uint32_t cls = Q_COUNT;
-                        if (pending) cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
-                        const f4 hit{bt, hud / hdet, hvd / hdet, asf(bid)};
-#pragma unroll
-                        for (uint32_t c = 0; c < Q_COUNT; ++c)
-                        {
-                            if (!((out.class_mask >> c) & 1u)) continue;
-                            const uint64_t m = __ballot(cls == c);
-                            if (m == 0ull) continue;
-                            const Placement pl = c == Q_TERMINAL
-                                ? wave_reserve(bin_region[c], out.n_shade + c, (uint32_t)__popcll(m), rsize, out.cap_term, out.overflow)
-                                : wave_reserve_striped(bin_region[c], out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), out.cap_shade, out.overflow);
-                            if (cls == c)
-                            {
-                                const uint32_t pos = place(pl, mbcnt64(m));
-                                if (c == Q_TERMINAL)
-                                {
-                                    out.hits[ray_idx] = hit;
-                                    out.q_term[pos] = make_uint2(ray_idx, pid);
-                                }
-                                else
-                                {
-                                    f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride + pos;
-                                    nt_store(qa, f4{w.d.x, w.d.y, w.d.z, asf(pid)});
-                                    nt_store(qa + out.q_stride, hit);
-                                    if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)out.q_stride, f4{w.o.x, w.o.y, w.o.z, 0.0f});
-                                }
-                            }
-                        }
-                    }
-                }
-                else
-                {
-                    if (pending) out.hits[ray_idx] = f4{bt, hud / hdet, hvd / hdet, asf(bid)};
-                }
-                pending = false;
-            }
-            if (no_more) break;
-            // ---- refill idle lanes from the wave's private range
-            const uint64_t idle = ~act;
-            uint32_t first;
-            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(idle), first);
-            const uint32_t rank = mbcnt64(idle);
-            if (!active && rank < take)
-            {
-                const uint32_t mine = fetch_slot<LDS_SCENE>(first + rank, plan.n);
-                const f4 b = rb[mine];
-                ray_idx = mine;
-                pid = asu(b.w);
-                if (pid != HOLE) {
-                valid_rays += 1u;
-                if (MODE == CLOSEST_PRIMARY)
-                {
-                    w.o = out.eye;
-                    t_max = asf(0x7f800000u);
-                }
-                else
-                {
-                    const f4 a = ra[mine];
-                    w.o = xyz(a);
-                    t_max = a.w;
-                }
-                w.d = xyz(b);
-                w.inv = rcp3(w.d);
-                ray_finite = finite3(w.o) && finite3(w.d);
-                bid = MISS_ID;
-                bt = asf(0x7f800000u);
-                hud = 0.0f;
-                hvd = 0.0f;
-                hdet = 1.0f;
-                in_blas = false;
-                parked = false;
-                r_inst = MISS_ID;
-                head = tail = 0u;
-                sp = stk.empty();
-                float te;
-                const uint4 root0 = bl.nodes[2u * root];
-                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
-                if (ok)
-                {
-                    stk.put(sp, make_uint2(root0.w, 0u));    // tlas.rs:74: the root goes in with t_enter 0
-                    sp = stk.up(sp);
-                    active = true;
-                    // every instance is the identity: one object-space image of the ray serves them all (instance 0's matrix is everybody's)
-                    if (IDENT) { uint32_t unused; ob = to_object(bl, 0u, w, ray_finite, unused); }
-                }
-                else { pending = true; }
-                } // not a hole
-            }
-            act = __ballot(active);
-            PT_TT_END(tt_service);
-            if (act == 0ull) continue;
-            if (PT_RESERVICE && take < (uint32_t)__popcll(idle) && !wr.drained && (uint32_t)__popcll(act) <= (uint32_t)Refill<LDS_SCENE>::kBelow) continue;
-        }
-
-#pragma unroll 1
-        for (int it = 0; it < Refill<LDS_SCENE>::kSteps; ++it)
-        {
-            PT_TT_BEGIN();
-            if (active)
-            {
-                if (in_blas && sp == blas_base) in_blas = false; // BLAS::intersect returned  blas.rs:255
-                if (sp == stk.empty() && head == tail) { active = false; pending = true; }
-            }
-            const bool has_c = active && head != tail;
-            const bool can_b = active && sp != stk.empty() && !parked && (tail - head) <= (uint32_t)(PT_CAND_SLOTS - 2);
-            const uint64_t ml = __ballot(has_c), mb = __ballot(can_b);
-#if PT_STEP_STATS
-            if ((ml | mb) != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(__ballot(active)); st_lane_park += (uint32_t)__popcll(__ballot(active && !has_c && !can_b)); }
-#endif
-            if (ml != 0ull && ((uint32_t)__popcll(ml) >= (uint32_t)PT_LEAF_VOTE || mb == 0ull))
-            {
-                // ---- leaf round: the next candidate of every lane that holds one, in the order the reference would have popped them
-#if PT_STEP_STATS
-                if (lane_id() == (uint32_t)__builtin_ctzll(ml)) st_wave_leaf += 1u;
-                st_lane_leaf += has_c ? 1u : 0u;
-#endif
-                if (has_c)
-                {
-                    const uint4 c = ring.get(head);
-                    head += 1u;
-                    if (head == tail) parked = false;
-                    const float t_est = asf(c.y);
-                    // the TLAS leaf's pop test (tlas.rs:80-83), made when the instance's first leaf comes up
-                    if (c.z != r_inst) { r_inst = c.z; r_pruned = asf(c.w) > t_max; }
-                    if (!r_pruned && !(t_est > t_max))         // the leaf's own pop test  blas.rs:222-225
-                    {
-#if PT_STEP_STATS
-                        st_lane_test += 1u;
-#endif
-                        uint32_t first, count;
-                        leaf_range(bl, c.x >> NODE_KIND_SHIFT, c.x & NODE_PAYLOAD_MASK, first, count);
-                        const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
-                        const float t_min = PT_EPSILON - t_est;
-                        const uint32_t c_inst = c.z;
-                        auto accept = [&](const TriEval& e, uint32_t tri) {
-                            if (e.uv_ok && tri_in_range(e, t_min, t_max - t_est))
-                            {
-                                bt = e.td / e.det + t_est;     // primitive.rs:158-170
-                                hud = e.ud;
-                                hvd = e.vd;
-                                hdet = e.det;
-                                t_max = bt;
-                                bid = (c_inst << prim_bits) | tri;
-                            }
-                        };
-                        uint32_t k = 0;
-                        for (; k + 1u < count; k += 2u)
-                        {
-                            const uint4* tp = bl.tris + 3u * (first + k);
-                            const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
-                            accept(ea, first + k);
-                            accept(eb, first + k + 1u);
-                        }
-                        if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
-                        if (bt != bt) { sp = stk.empty(); in_blas = false; head = tail; parked = false; } // NaN t_max: nothing else can be accepted anywhere
-                    }
-                }
-                PT_TT_END(tt_leaf);
-            }
-            else if (mb != 0ull)
-            {
-                // ---- branch step
-#if PT_STEP_STATS
-                if (lane_id() == (uint32_t)__builtin_ctzll(mb)) st_wave_branch += 1u;
-                st_lane_branch += can_b ? 1u : 0u;
-#endif
-                if (can_b)
-                {
-                    sp = stk.down(sp);
-                    const uint2 e = stk.get(sp);
-                    uint32_t link = e.x;
-                    float ts = asf(e.y);
-                    bool go = !(ts > t_max);                         // tlas.rs:80-83 / blas.rs:222-225 with a t_max that is not smaller than the reference's
-                    if (go && (link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
-                    {
-                        if (!IDENT && head != tail) { sp = stk.up(sp); parked = true; go = false; } // the FIFO's entries still need the old object-space ray
-                        else
-                        {
-                            inst = link & NODE_PAYLOAD_MASK;
-                            ts_inst = ts;
-                            uint32_t blas_root;
-                            if (IDENT) blas_root = bl.inst[7u * inst + 6u].x;
-                            else ob = to_object(bl, inst, w, ray_finite, blas_root);
-                            in_blas = true;
-                            blas_base = sp;
-                            link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3]; // blas.rs:217: the root goes in with t_enter 0, no box test
-                            ts = 0.0f;
-                        }
-                    }
-                    if (go)
-                    {
-                        uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
-                        if (kind & 1u) { ring.put(tail, make_uint4(link, asu(ts), inst, asu(ts_inst))); tail += 1u; } // a leaf that was the farther child, or a BLAS that is one leaf
-#pragma unroll 1
-                        for (int lvl = 0; lvl < PT_BRANCH_LEVELS2 && kind == NODE_BRANCH; ++lvl)
-                        {
-                            const uint4* cp = bl.nodes + 2u * payload;
-                            const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
-                            const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
-                            float tl, tr;
-                            const bool hl = slab(l0, l1, o, inv, t_max, tl);
-                            const bool hr = slab(r0, r1, o, inv, t_max, tr);
-                            kind = NODE_INSTANCE; // nothing more in this step unless the nearer child is a branch
-                            if (hl || hr)
-                            {
-                                // push_to_stack  blas.rs:133-162: the farther child underneath (ties: left underneath, right popped first)
-                                const bool both = hl && hr, left_near = hl && (tl < tr || !hr);
-                                const uint2 near = left_near ? make_uint2(l0.w, asu(tl)) : make_uint2(r0.w, asu(tr));
-                                const uint2 far = left_near ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
-                                const uint32_t nk = near.x >> NODE_KIND_SHIFT;
-                                if (nk & 1u)
-                                {
-                                    // the nearer child is a leaf: it is what the reference pops next
-                                    ring.put(tail, make_uint4(near.x, near.y, inst, asu(ts_inst)));
-                                    tail += 1u;
-                                    if (both)
-                                    {
-                                        // ... and if the farther one is a leaf too it is popped right after it
-                                        if ((far.x >> NODE_KIND_SHIFT) & 1u) { ring.put(tail, make_uint4(far.x, far.y, inst, asu(ts_inst))); tail += 1u; }
-                                        else { stk.put(sp, far); sp = stk.up(sp); }
-                                    }
-                                }
-                                else
-                                {
-                                    if (both) { stk.put(sp, far); sp = stk.up(sp); }
-                                    if (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS2) { kind = NODE_BRANCH; payload = near.x & NODE_PAYLOAD_MASK; }
-                                    else { stk.put(sp, near); sp = stk.up(sp); }
-                                }
-                            }
-                        }
-                    }
-                }
-                PT_TT_END(tt_branch);
-            }
-            else break; // every lane that had a ray has just finished it
-        }
-    }
-#if PT_STEP_STATS == 2
-    {
-        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
-        const uint64_t tt_total = __builtin_readcyclecounter() - tt_start;
-        if (lane_id() == 0u)
-        {
-            atomicAdd(line + 16, n_service); atomicAdd(line + 17, (uint32_t)(tt_service >> 6)); atomicAdd(line + 18, (uint32_t)(tt_branch >> 6));
-            atomicAdd(line + 19, (uint32_t)(tt_leaf >> 6)); atomicAdd(line + 20, (uint32_t)(tt_total >> 6));
-        }
-    }
-#endif
-    if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
-    {
-        const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
-        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) out.q_term[i] = make_uint2(HOLE, 0u);
-#pragma unroll
-        for (uint32_t c = 1; c < Q_COUNT; ++c)
-        {
-            f4* const qa = out.q_base + (size_t)(3u * ((out.q_class_slot >> (4u * c)) & 0xfu)) * out.q_stride;
-            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
-        }
-    }
-#if PT_STEP_STATS
-    // words 8..15 of the cursor lines: wave-steps, lanes holding a ray in them, lanes expanding a branch, lanes taking a candidate, lanes
-    // testing triangles, wave-steps that were branch steps / leaf rounds, lanes that could do neither (tools/step_stats.py)
-    {
-        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
-        if (lane_id() == 0u) { atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); atomicAdd(line + 15, st_lane_park); }
-        uint32_t a = st_lane_branch, b = st_lane_leaf, c2 = st_lane_test;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c2 += __shfl_xor(c2, off); }
-        if (lane_id() == 0u) { atomicAdd(line + 10, a); atomicAdd(line + 11, b); atomicAdd(line + 12, c2); }
-        a = st_wave_branch; b = st_wave_leaf;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-        if (lane_id() == 0u) { atomicAdd(line + 13, a); atomicAdd(line + 14, b); }
-    }
-#endif
-    if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
-}
-
-// ------------------------------------------------------------------------------------------------ closest hit, leaves deferred, lanes streamed
-// k_closest2's wave-steps are uniform, but its lanes are not busy: a ray's set-up (three divisions, the root box, the object-space image)
-// and its retirement (two divisions, the class's queue slot, 48 bytes of stores) are expensive, so they are done for many lanes at a
-// time — which means waiting until many lanes are idle: 43 of 64 lanes hold a ray on average, 35 do work in a step, and the service runs
-// with ~24 lanes (tools/step_stats2.py: 27 % of the wave time is service, 64 % steps).  Here every lane has two more sets of registers:
-//   * a NEXT ray, already set up (origin, direction, reciprocal, t_max, indices, whether it meets the root box), and
-//   * the RESULT of the ray it finished last (t, the (u, v) numerators and determinant, hit id, indices).
-// A lane that finishes its ray parks the result, takes its next ray and goes on within one wave-step.  Set-up runs as a batch when
-// PT_STREAM_IN lanes have no next ray, retirement as a batch when PT_STREAM_OUT lanes hold a result (or a lane with a result in hand
-// finishes another ray): both at 60–100 % lane occupancy instead of 37 %, and the steps in between run with the lanes full.
-// What the retirement needs of the ray itself (direction, origin) it reads back from the ray queue by ray index.
-// Everything the service sections need of the launch description is read through the kernel-argument segment when they run
-// (s_load, scalar cache) instead of living in scalar registers across the traversal loop (k_closest2 spills 71 of them).
-#ifndef PT_STREAM_IN
-#define PT_STREAM_IN 32
-#endif
-#ifndef PT_STREAM_OUT
-#define PT_STREAM_OUT 40
-#endif
-#ifndef PT_STREAM_STEPS
-#define PT_STREAM_STEPS 2   // wave-steps between two looks at the lanes' buffers
-#endif
-// the kernel's single argument as it lies in the kernel-argument segment; the empty asm keeps the compiler from hoisting the loads
-// made through the pointer out of the section that makes them
-[[maybe_unused]] __device__ __forceinline__ ClosestKArgsPtr cold_args()
-{
-    ClosestKArgsPtr p = (ClosestKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-template <bool LDS_SCENE, int MODE, bool SPILL, bool IDENT>
-__global__ void __launch_bounds__(256, LDS_SCENE ? PT_WAVES_LDS_BVH : PT_WAVES_GLOBAL_BVH) k_closest3(const ClosestKArgs a)
-{
-    static_assert(MODE != CLOSEST_LIGHTS, "the fused NEE chain stays on k_closest");
-    extern __shared__ uint4 smem[];
-    const FetchPlan plan = fetch_plan(min(*a.n_ptr, a.cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER);
-    if (blockIdx.x >= plan.blocks) return;
-    uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
-    const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, a.sv);
-    const CandRing ring = CandRing::make(smem, blob_words, a.sv);
-    const uint32_t prim_bits = a.sv.prim_bits;
-    uint32_t* const heads = a.heads;
-
-    // the ray in flight
-    bool active = false, ray_finite = false, in_blas = false, parked = false, r_pruned = false;
-    uint32_t ray_idx = 0, pid = 0;
-    LaneRay w{}, ob{};
-    float t_max = 0.0f, bt = 0.0f, ts_inst = 0.0f;
-    float hud = 0.0f, hvd = 0.0f, hdet = 1.0f;
-    uint32_t bid = MISS_ID, sp = stk.empty(), blas_base = 0, inst = 0, r_inst = MISS_ID;
-    uint32_t head = 0, tail = 0;
-    // the next ray, set up
-    bool nx_valid = false;
-    LaneRay nx{};
-    float nx_tmax = 0.0f;
-    uint32_t nx_ridx = 0, nx_pid = 0, nx_flags = 0; // flags: bit 0 the ray meets the root box, bit 1 origin and direction are finite
-    // the last result
-    bool res_valid = false;
-    uint32_t res_ridx = 0, res_pid = 0, res_bid = MISS_ID;
-    float res_bt = 0.0f, res_hud = 0.0f, res_hvd = 0.0f, res_hdet = 1.0f;
-
-    WaveRange wr = first_range(plan, heads);
-    uint32_t valid_rays = 0;
-#if PT_STEP_STATS
-    uint32_t st_iter = 0, st_lane_active = 0, st_lane_branch = 0, st_lane_leaf = 0, st_lane_test = 0, st_wave_branch = 0, st_wave_leaf = 0, st_lane_park = 0;
-    uint32_t st_n_out = 0, st_lanes_out = 0, st_n_in = 0, st_lanes_in = 0, st_bound = 0;
-#endif
-    Region bin_region[Q_COUNT];
-#pragma unroll
-    for (uint32_t c = 0; c < Q_COUNT; ++c) bin_region[c] = Region{0u, 0u};
-    uint32_t stripe_rot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    for (;;)
-    {
-        // ---- look at the lanes' buffers
-        bool fin = false;
-        if (active)
-        {
-            if (in_blas && sp == blas_base) in_blas = false;   // BLAS::intersect returned  blas.rs:255
-            fin = sp == stk.empty() && head == tail;
-        }
-        auto park_result = [&]() {
-            res_ridx = ray_idx; res_pid = pid; res_bt = bt; res_hud = hud; res_hvd = hvd; res_hdet = hdet; res_bid = bid;
-            res_valid = true;
-            active = false;
-        };
-        if (fin && !res_valid) { park_result(); fin = false; }
-        const uint64_t m_stuck = __ballot(fin);      // finished, but the result of the ray before is still in hand
-        const uint64_t m_res = __ballot(res_valid);
-        const bool no_more = wr.drained && wr.cur >= wr.end;
-        uint64_t m_nx = __ballot(nx_valid);
-        const uint64_t m_act = __ballot(active);
-#if PT_STEP_STATS
-        st_bound += 1u;
-#endif
-        if (m_res != 0ull && (m_stuck != 0ull || (uint32_t)__popcll(m_res) >= (uint32_t)PT_STREAM_OUT || (m_act == 0ull && (no_more || m_nx == 0ull))))
-        {
-            // ---- retirement batch (the logic of k_closest's retire section, on the parked results)
-#if PT_STEP_STATS
-            st_n_out += 1u; st_lanes_out += (uint32_t)__popcll(m_res);
-#endif
-            const ClosestKArgsPtr k = cold_args();
-            bool pending = res_valid;
-            f3 rd{0.0f, 0.0f, 0.0f}, ro{0.0f, 0.0f, 0.0f};
-            if (pending)
-            {
-                rd = xyz(a.rb[res_ridx]);
-                if (MODE == CLOSEST_PRIMARY) ro = f3{k->out.eye.x, k->out.eye.y, k->out.eye.z};
-                else if (MODE == CLOSEST_WORLD) ro = xyz(a.ra[res_ridx]);
-            }
-            if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
-            {
-                const uint32_t finalize_miss = k->out.finalize_miss;
-                uint64_t qm = m_res;
-                if (MODE == CLOSEST_PRIMARY)
-                {
-                    uint8_t* const occl = k->out.occl;
-                    const bool missed = pending && res_bid == MISS_ID && finalize_miss != 0u;
-                    if (pending) occl[res_ridx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
-                    if (pending && res_bid == MISS_ID)
-                    {
-                        // defaults of integrator.rs:156-157 (with an environment map the terminal pass shades the miss)
-                        const uint32_t keep_id_from = k->out.keep_id_from, keep_pos_from = k->out.keep_pos_from;
-                        if (res_ridx >= keep_id_from) k->out.first_id[res_ridx - keep_id_from] = 255u;
-                        if (res_ridx >= keep_pos_from)
-                        {
-                            const f3 far = fma3(rd, bc3(1e5f), ro);
-                            k->out.first_pos[res_ridx - keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
-                        }
-                    }
-                    qm = __ballot(pending && !missed);
-                    pending = pending && !missed;
-                }
-                if (MODE == CLOSEST_WORLD)
-                {
-                    // paths that end at this hit or miss are finished here (integrator.rs:207-214, 263-266): see k_closest
-                    bool ends = false, emissive = false;
-                    uint32_t mat_id = 0;
-                    if (pending)
-                    {
-                        if (res_bid == MISS_ID) ends = finalize_miss != 0u;
-                        else
-                        {
-                            const uint4 meta = bl.inst[7u * (res_bid >> prim_bits) + 6u];
-                            emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
-                            mat_id = meta.z;
-                        }
-                    }
-                    if (__ballot(ends) != 0ull)
-                    {
-                        const DPathRec* const recs = k->out.rec;
-                        const uint32_t enable_nee = k->out.enable_nee;
-                        if (ends)
-                        {
-                            const DPathRec& rec = recs[res_pid];
-                            const f4 acc4 = rec.acc;
-                            const uint32_t flags = asu(acc4.w);
-                            if (!(flags & FLAG_BSDF_CAST))
-                            {
-                                f3 acc = xyz(acc4);
-                                if (flags & FLAG_NEE_PENDING) acc = acc + xyz(rec.nee_pw) * (xyz(rec.nee_e) + f3{0.0f, 0.0f, 0.0f}); // integrator.rs:231-234
-                                const f3 pw = xyz(rec.pw);
-                                if (!emissive) acc = acc + f3{0.006f, 0.006f, 0.006f} * pw;
-                                else if (!enable_nee || (flags & FLAG_LAST_DELTA))
-                                {
-                                    const DMaterial& m = a.sv.materials[mat_id];
-                                    acc = fma3(f3{m.colour[0], m.colour[1], m.colour[2]}, pw, acc);
-                                }
-                                k->out.radiance[res_pid] = f4{acc.x, acc.y, acc.z, 0.0f};
-                                pending = false;
-                            }
-                        }
-                    }
-                    qm = __ballot(pending);
-                }
-                if (qm != 0ull)
-                {
-                    uint32_t cls = Q_COUNT;
-                    if (pending) cls = res_bid != MISS_ID ? (bl.inst[7u * (res_bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
-                    const f4 hit{res_bt, res_hud / res_hdet, res_hvd / res_hdet, asf(res_bid)};
-                    const uint32_t class_mask = k->out.class_mask, q_stride = k->out.q_stride, q_class_slot = k->out.q_class_slot;
-                    const Stripes stripes = stripes_for(plan.n);
-#pragma unroll
-                    for (uint32_t c = 0; c < Q_COUNT; ++c)
-                    {
-                        if (!((class_mask >> c) & 1u)) continue;
-                        const uint64_t m = __ballot(cls == c);
-                        if (m == 0ull) continue;
-                        Placement pl;
-                        if (c == Q_TERMINAL)
-                        {
-                            const uint32_t rsize = finalize_miss != 0u ? 64u : region_size(plan.n, plan.blocks * (blockDim.x >> 6), 64u);
-                            pl = wave_reserve(bin_region[c], k->out.n_shade + c, (uint32_t)__popcll(m), rsize, k->out.cap_term, k->out.overflow);
-                        }
-                        else pl = wave_reserve_striped(bin_region[c], k->out.tails + c * kTailWordsPerQueue, stripes, stripe_rot, (uint32_t)__popcll(m), k->out.cap_shade, k->out.overflow);
-                        uint32_t my_rank = mbcnt64(m);
-#if PT_SORT_RETIRE
-                        // experiment: slots in ray-index order instead of lane order
-                        {
-                            my_rank = 0u;
-                            for (uint64_t mm = m; mm != 0ull; mm &= mm - 1ull)
-                            {
-                                const uint32_t other = __builtin_amdgcn_readlane(res_ridx, (int)__builtin_ctzll(mm));
-                                my_rank += other < res_ridx ? 1u : 0u;
-                            }
-                        }
-#endif
-                        if (cls == c)
-                        {
-                            const uint32_t pos = place(pl, my_rank);
-                            if (c == Q_TERMINAL)
-                            {
-                                k->out.hits[res_ridx] = hit;
-                                k->out.q_term[pos] = make_uint2(res_ridx, res_pid);
-                            }
-                            else
-                            {
-                                f4* const qa = k->out.q_base + (size_t)(3u * ((q_class_slot >> (4u * c)) & 0xfu)) * q_stride + pos;
-                                nt_store(qa, f4{rd.x, rd.y, rd.z, asf(res_pid)});
-                                nt_store(qa + q_stride, hit);
-                                if (MODE != CLOSEST_PRIMARY) nt_store(qa + 2u * (size_t)q_stride, f4{ro.x, ro.y, ro.z, 0.0f});
-                            }
-                        }
-                    }
-                }
-            }
-            else
-            {
-                if (pending) k->out.hits[res_ridx] = f4{res_bt, res_hud / res_hdet, res_hvd / res_hdet, asf(res_bid)};
-            }
-            res_valid = false;
-            if (fin) park_result();   // the lanes that were waiting for their result registers
-        }
-        // ---- set-up batch: next rays for the lanes that have none
-        if (!no_more && ((uint32_t)__popcll(~m_nx) >= (uint32_t)PT_STREAM_IN || __ballot(active) == 0ull))
-        {
-            const uint64_t need = ~m_nx;
-            uint32_t first;
-            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(need), first);
-            const uint32_t rank = mbcnt64(need);
-#if PT_STEP_STATS
-            st_n_in += 1u; st_lanes_in += take;
-#endif
-            if (!nx_valid && rank < take)
-            {
-                const uint32_t mine = fetch_slot<LDS_SCENE>(first + rank, plan.n);
-                const f4 b = a.rb[mine];
-                nx_ridx = mine;
-                nx_pid = asu(b.w);
-                if (nx_pid != HOLE)
-                {
-                    valid_rays += 1u;
-                    if (MODE == CLOSEST_PRIMARY)
-                    {
-                        const ClosestKArgsPtr k = cold_args();
-                        nx.o = f3{k->out.eye.x, k->out.eye.y, k->out.eye.z};
-                        nx_tmax = asf(0x7f800000u);
-                    }
-                    else
-                    {
-                        const f4 ao = a.ra[mine];
-                        nx.o = xyz(ao);
-                        nx_tmax = ao.w;
-                    }
-                    nx.d = xyz(b);
-                    nx.inv = rcp3(nx.d);
-                    const bool finite = finite3(nx.o) && finite3(nx.d);
-                    float te;
-                    const uint4 root0 = bl.nodes[2u * a.root];
-                    const bool ok = (nx_tmax == nx_tmax) && slab(root0, bl.nodes[2u * a.root + 1u], nx.o, nx.inv, nx_tmax, te); // tlas.rs:68-72
-                    nx_flags = (ok ? 1u : 0u) | (finite ? 2u : 0u);
-                    nx_valid = true;
-                }
-            }
-        }
-        // ---- a lane without a ray takes its next one
-        if (!active && nx_valid)
-        {
-            ray_idx = nx_ridx;
-            pid = nx_pid;
-            w = nx;
-            t_max = nx_tmax;
-            ray_finite = (nx_flags & 2u) != 0u;
-            bid = MISS_ID;
-            bt = asf(0x7f800000u);
-            hud = 0.0f;
-            hvd = 0.0f;
-            hdet = 1.0f;
-            in_blas = false;
-            parked = false;
-            r_inst = MISS_ID;
-            head = tail = 0u;
-            sp = stk.empty();
-            if (nx_flags & 1u)
-            {
-                stk.put(sp, make_uint2(reinterpret_cast<const uint32_t*>(bl.nodes + 2u * a.root)[3], 0u)); // tlas.rs:74: the root goes in with t_enter 0
-                sp = stk.up(sp);
-                // every instance is the identity: one object-space image of the ray serves them all (instance 0's matrix is everybody's)
-                if (IDENT) { uint32_t unused; ob = to_object(bl, 0u, w, ray_finite, unused); }
-            }
-            active = true;
-            nx_valid = false;
-        }
-        if (__ballot(active || nx_valid || res_valid) == 0ull)
-        {
-            if (no_more) break;
-            continue; // (a set-up batch that brought nothing but holes)
-        }
-
-#pragma unroll 1
-        for (int it = 0; it < PT_STREAM_STEPS; ++it)
-        {
-            if (it != 0 && active && in_blas && sp == blas_base) in_blas = false;
-            const bool has_c = active && head != tail;
-            const bool can_b = active && sp != stk.empty() && !parked && (tail - head) <= (uint32_t)(PT_CAND_SLOTS - 2);
-            const uint64_t ml = __ballot(has_c), mb = __ballot(can_b);
-#if PT_STEP_STATS
-            if ((ml | mb) != 0ull) { st_iter += 1u; st_lane_active += (uint32_t)__popcll(__ballot(active)); st_lane_park += (uint32_t)__popcll(__ballot(active && !has_c && !can_b)); }
-#endif
-            if (ml != 0ull && ((uint32_t)__popcll(ml) >= (uint32_t)PT_LEAF_VOTE || mb == 0ull))
-            {
-                // ---- leaf round (k_closest2)
-#if PT_STEP_STATS
-                if (lane_id() == (uint32_t)__builtin_ctzll(ml)) st_wave_leaf += 1u;
-                st_lane_leaf += has_c ? 1u : 0u;
-#endif
-                if (has_c)
-                {
-                    const uint4 c = ring.get(head);
-                    head += 1u;
-                    if (head == tail) parked = false;
-                    const float t_est = asf(c.y);
-                    if (c.z != r_inst) { r_inst = c.z; r_pruned = asf(c.w) > t_max; }   // the TLAS leaf's pop test  tlas.rs:80-83
-                    if (!r_pruned && !(t_est > t_max))                                    // the leaf's own  blas.rs:222-225
-                    {
-#if PT_STEP_STATS
-                        st_lane_test += 1u;
-#endif
-                        uint32_t first, count;
-                        leaf_range(bl, c.x >> NODE_KIND_SHIFT, c.x & NODE_PAYLOAD_MASK, first, count);
-                        const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
-                        const float t_min = PT_EPSILON - t_est;
-                        const uint32_t c_inst = c.z;
-                        auto accept = [&](const TriEval& e, uint32_t tri) {
-                            if (e.uv_ok && tri_in_range(e, t_min, t_max - t_est))
-                            {
-                                bt = e.td / e.det + t_est;     // primitive.rs:158-170
-                                hud = e.ud;
-                                hvd = e.vd;
-                                hdet = e.det;
-                                t_max = bt;
-                                bid = (c_inst << prim_bits) | tri;
-                            }
-                        };
-                        uint32_t kk = 0;
-                        for (; kk + 1u < count; kk += 2u)
-                        {
-                            const uint4* tp = bl.tris + 3u * (first + kk);
-                            const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
-                            accept(ea, first + kk);
-                            accept(eb, first + kk + 1u);
-                        }
-                        if (kk < count) accept(tri_eval(bl.tris + 3u * (first + kk), mo, ob.d), first + kk);
-                        if (bt != bt) { sp = stk.empty(); in_blas = false; head = tail; parked = false; } // NaN t_max: nothing else can be accepted anywhere
-                    }
-                }
-            }
-            else if (mb != 0ull)
-            {
-                // ---- branch step (k_closest2)
-#if PT_STEP_STATS
-                if (lane_id() == (uint32_t)__builtin_ctzll(mb)) st_wave_branch += 1u;
-                st_lane_branch += can_b ? 1u : 0u;
-#endif
-                if (can_b)
-                {
-                    sp = stk.down(sp);
-                    const uint2 e = stk.get(sp);
-                    uint32_t link = e.x;
-                    float ts = asf(e.y);
-                    bool go = !(ts > t_max);
-                    if (go && (link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
-                    {
-                        if (!IDENT && head != tail) { sp = stk.up(sp); parked = true; go = false; }
-                        else
-                        {
-                            inst = link & NODE_PAYLOAD_MASK;
-                            ts_inst = ts;
-                            uint32_t blas_root;
-                            if (IDENT) blas_root = bl.inst[7u * inst + 6u].x;
-                            else ob = to_object(bl, inst, w, ray_finite, blas_root);
-                            in_blas = true;
-                            blas_base = sp;
-                            link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3];
-                            ts = 0.0f;
-                        }
-                    }
-                    if (go)
-                    {
-                        uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
-                        if (kind & 1u) { ring.put(tail, make_uint4(link, asu(ts), inst, asu(ts_inst))); tail += 1u; }
-#pragma unroll 1
-                        for (int lvl = 0; lvl < PT_BRANCH_LEVELS2 && kind == NODE_BRANCH; ++lvl)
-                        {
-                            const uint4* cp = bl.nodes + 2u * payload;
-                            const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
-                            const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
-                            float tl, tr;
-                            const bool hl = slab(l0, l1, o, inv, t_max, tl);
-                            const bool hr = slab(r0, r1, o, inv, t_max, tr);
-                            kind = NODE_INSTANCE;
-                            if (hl || hr)
-                            {
-                                const bool both = hl && hr, left_near = hl && (tl < tr || !hr);
-                                const uint2 near = left_near ? make_uint2(l0.w, asu(tl)) : make_uint2(r0.w, asu(tr));
-                                const uint2 far = left_near ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
-                                const uint32_t nk = near.x >> NODE_KIND_SHIFT;
-                                if (nk & 1u)
-                                {
-                                    ring.put(tail, make_uint4(near.x, near.y, inst, asu(ts_inst)));
-                                    tail += 1u;
-                                    if (both)
-                                    {
-                                        if ((far.x >> NODE_KIND_SHIFT) & 1u) { ring.put(tail, make_uint4(far.x, far.y, inst, asu(ts_inst))); tail += 1u; }
-                                        else { stk.put(sp, far); sp = stk.up(sp); }
-                                    }
-                                }
-                                else
-                                {
-                                    if (both) { stk.put(sp, far); sp = stk.up(sp); }
-                                    if (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS2) { kind = NODE_BRANCH; payload = near.x & NODE_PAYLOAD_MASK; }
-                                    else { stk.put(sp, near); sp = stk.up(sp); }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            else break; // every lane's ray is finished: back to the buffers
-        }
-    }
-    if (MODE == CLOSEST_WORLD || MODE == CLOSEST_PRIMARY)
-    {
-        const ClosestKArgsPtr k = cold_args();
-        const uint32_t q_stride = k->out.q_stride, q_class_slot = k->out.q_class_slot;
-        const f4 hole{0.0f, 0.0f, 0.0f, asf(HOLE)};
-        uint2* const q_term = k->out.q_term;
-        for (uint32_t i = bin_region[Q_TERMINAL].cur + lane_id(); i < bin_region[Q_TERMINAL].end; i += 64u) q_term[i] = make_uint2(HOLE, 0u);
-#pragma unroll
-        for (uint32_t c = 1; c < Q_COUNT; ++c)
-        {
-            f4* const qa = k->out.q_base + (size_t)(3u * ((q_class_slot >> (4u * c)) & 0xfu)) * q_stride;
-            for (uint32_t i = bin_region[c].cur + lane_id(); i < bin_region[c].end; i += 64u) qa[i] = hole;
-        }
-    }
-#if PT_STEP_STATS
-    {
-        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        uint32_t* line = heads + ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
-        if (lane_id() == 0u)
-        {
-            atomicAdd(line + 8, st_iter); atomicAdd(line + 9, st_lane_active); atomicAdd(line + 15, st_lane_park);
-            atomicAdd(line + 16, st_n_out); atomicAdd(line + 17, st_lanes_out); atomicAdd(line + 18, st_n_in); atomicAdd(line + 19, st_lanes_in); atomicAdd(line + 20, st_bound);
-        }
-        uint32_t x = st_lane_branch, y = st_lane_leaf, z = st_lane_test;
-        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); z += __shfl_xor(z, off); }
-        if (lane_id() == 0u) { atomicAdd(line + 10, x); atomicAdd(line + 11, y); atomicAdd(line + 12, z); }
-        x = st_wave_branch; y = st_wave_leaf;
-        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
-        if (lane_id() == 0u) { atomicAdd(line + 13, x); atomicAdd(line + 14, y); }
-    }
-#endif
-    if (MODE != CLOSEST_HOOK) add_tally(heads, valid_rays, HEAD_TALLY0);
 }
 
 // ------------------------------------------------------------------------------------------------ any hit
@@ -2235,7 +1212,7 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                                          uint32_t* __restrict__ heads, uint32_t* __restrict__ occluded,
                                          f4* __restrict__ radiance)
 {
-    constexpr bool LDS_SCENE = BVH != 0, OCT = BVH == 2; // BVH: 0 in global memory, 1 in LDS, 2 in LDS with octant copies of the nodes (stage_scene)
+    constexpr bool LDS_SCENE = BVH != 0; // BVH: 0 in global memory, 1 in LDS
     const FetchPlan plan = fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY);
     if (blockIdx.x >= plan.blocks) return;
     const Stack8<SPILL> stk = Stack8<SPILL>::make(smem, blob_words, sv); // entries (node, entry distance of its box)
@@ -2243,7 +1220,6 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
     bool active = false, ray_finite = false;
     uint32_t out_idx = 0, valid_rays = 0;
     LaneRay w{}, ob{};
-    uint32_t nb_w = 0, nb_o = 0; // OCT: word offsets of the node copies of the world-space / object-space ray's direction octant
     float t_max = 0.0f;
     uint32_t sp = stk.empty(), blas_base = 0;
     // ANY_SHADOW: `occluded` is PathState::rec: a blocked shadow ray erases the path's explicit-light candidate (integrator.rs:55-56,73)
@@ -2280,83 +1256,6 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
 #endif
     WaveRange wr = first_range(plan, heads);
 
-#if PT_ANY_STREAM
-    // STREAMED lanes (as k_closest3, without its result registers: an any-hit ray's result is one conditional store).  Every lane holds a
-    // NEXT ray, already set up — three correctly rounded reciprocals, the root box, 32 bytes of loads: most of what a short shadow ray
-    // costs — so that set-up runs as a batch when PT_ANY_STREAM_IN lanes have none, at 50-100 % lane occupancy instead of the ~24 lanes
-    // of a refill, and a lane whose ray ends goes on with its next one within PT_ANY_STREAM_STEPS wave-steps.
-    bool nx_valid = false;
-    LaneRay nx{};
-    float nx_tmax = 0.0f, nx_te = 0.0f;
-    uint32_t nx_out = 0, nx_flags = 0; // flags: bit 0 PATH_ENDS, bit 1 origin and direction are finite
-    for (;;)
-    {
-        const bool no_more = wr.drained && wr.cur >= wr.end;
-#if PT_WAVE_TIMES
-        if (no_more && tw_drained == 0u) tw_drained = (uint32_t)wall_clock64() | 1u;
-#endif
-        const uint64_t m_nx = __ballot(nx_valid);
-        if (!no_more && ((uint32_t)__popcll(~m_nx) >= (uint32_t)PT_ANY_STREAM_IN || __ballot(active) == 0ull))
-        {
-            const uint64_t need = ~m_nx;
-            uint32_t first;
-            const uint32_t take = claim_rays(wr, heads, plan, (uint32_t)__popcll(need), first);
-            const uint32_t rank = mbcnt64(need);
-            if (!nx_valid && rank < take)
-            {
-                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0>(first + rank, plan.n);
-                const f4 a = ra[mine], bb = rb[mine];
-                const uint32_t tag = asu(bb.w);
-                if (tag != HOLE)
-                {
-                    valid_rays += 1u;
-                    const bool ends = MODE == ANY_SHADOW && (tag & PATH_ENDS) != 0u;
-                    const uint32_t idx = (MODE == ANY_HOOK) ? mine : (tag & ~PATH_ENDS);
-                    nx.o = xyz(a);
-                    nx.d = xyz(bb);
-                    nx.inv = rcp3(nx.d);
-                    nx_tmax = a.w;
-                    const bool finite = finite3(nx.o) && finite3(nx.d);
-                    // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
-                    const uint32_t nbx = OCT ? octant_of(nx.inv) * bl.oct_stride : 0u;
-                    float te;
-                    const bool ok = (nx_tmax == nx_tmax) && slab_n<OCT>(bl.nodes[nbx + 2u * root], bl.nodes[nbx + 2u * root + 1u], nx.o, nx.inv, nx_tmax, te);
-                    if (ok)
-                    {
-                        nx_valid = true;
-                        nx_out = idx;
-                        nx_flags = (ends ? 1u : 0u) | (finite ? 2u : 0u);
-                        nx_te = te;
-                    }
-                    else put_result_at(idx, ends, 0u);
-                }
-            }
-        }
-        if (!active && nx_valid)
-        {
-            w = nx;
-            t_max = nx_tmax;
-            out_idx = nx_out;
-            path_ends = (nx_flags & 1u) != 0u;
-            ray_finite = (nx_flags & 2u) != 0u;
-            if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
-            in_blas = false;
-            sp = stk.empty();
-            stk.put(sp, make_uint2(reinterpret_cast<const uint32_t*>(bl.nodes + 2u * root)[3], asu(nx_te)));
-            sp = stk.up(sp);
-            active = true;
-            nx_valid = false;
-        }
-        if (__ballot(active || nx_valid) == 0ull)
-        {
-            if (no_more) break;
-            continue; // (a batch of holes, or of rays that all missed the root box)
-        }
-#pragma unroll 1
-        for (int it = 0; it < PT_ANY_STREAM_STEPS; ++it)
-        {
-            if (!active) continue;
-#else
     for (;;)
     {
         uint64_t act = __ballot(active);
@@ -2374,7 +1273,7 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             const uint32_t rank = mbcnt64(idle);
             if (!active && rank < take)
             {
-                const uint32_t mine = fetch_slot<LDS_SCENE, PT_SHUFFLE_WORLD_ONLY == 0>(first + rank, plan.n);
+                const uint32_t mine = first + rank;
                 const f4 a = ra[mine], b = rb[mine];
                 const uint32_t tag = asu(b.w);
                 if (tag != HOLE) {
@@ -2384,15 +1283,14 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 w.o = xyz(a);
                 w.d = xyz(b);
                 w.inv = rcp3(w.d);
-                if (OCT) nb_w = octant_of(w.inv) * bl.oct_stride;
                 ray_finite = finite3(w.o) && finite3(w.d);
                 t_max = a.w;
                 in_blas = false;
                 sp = stk.empty();
                 // the TLAS root's own box (tlas.rs:118-121); a NaN t_max fails every reference box test -> not occluded
                 float te;
-                const uint4 root0 = bl.nodes[nb_w + 2u * root];
-                const bool ok = (t_max == t_max) && slab_n<OCT>(root0, bl.nodes[nb_w + 2u * root + 1u], w.o, w.inv, t_max, te);
+                const uint4 root0 = bl.nodes[2u * root];
+                const bool ok = (t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te);
                 if (ok)
                 {
                     stk.put(sp, make_uint2(root0.w, asu(te)));
@@ -2417,7 +1315,6 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             }
 #endif
             if (!active) continue;
-#endif
             if (in_blas && sp == blas_base) in_blas = false;
             if (sp == stk.empty())
             {
@@ -2437,11 +1334,10 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
                 // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
                 uint32_t blas_root;
                 ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
-                if (OCT) nb_o = octant_of(ob.inv) * bl.oct_stride;
                 in_blas = true;
                 blas_base = sp;
-                const uint4 r0 = bl.nodes[nb_o + 2u * blas_root];
-                if (!slab_n<OCT>(r0, bl.nodes[nb_o + 2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                const uint4 r0 = bl.nodes[2u * blas_root];
+                if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
                 link = r0.w;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
@@ -2453,12 +1349,12 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
 #pragma unroll 1
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS_ANY && kind == NODE_BRANCH; ++lvl)
             {
-                const uint4* cp = bl.nodes + (in_blas ? nb_o : nb_w) + 2u * payload;
+                const uint4* cp = bl.nodes + 2u * payload;
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
-                const bool hl = slab_n<OCT>(l0, l1, o, inv, t_max, tl);
-                const bool hr = slab_n<OCT>(r0, r1, o, inv, t_max, tr);
+                const bool hl = slab(l0, l1, o, inv, t_max, tl);
+                const bool hr = slab(r0, r1, o, inv, t_max, tr);
                 if (hl && hr) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }   // left then right: right is popped first
                 kind = NODE_INSTANCE; // nothing more in this step unless the next child says otherwise
                 if (hl || hr)
@@ -2532,7 +1428,7 @@ __global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH_ANY : PT_WAVE
     extern __shared__ uint4 smem[];
     if (blockIdx.x >= fetch_plan(min(*n_ptr, cap_in), LDS_SCENE ? (uint32_t)PT_CHUNK_DIV : (uint32_t)PT_CHUNK_DIV_GLOBAL_BVH, (uint32_t)PT_TAPER_ANY).blocks) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(sv, gblob, smem, blob_words);
+    const Blob bl = stage_scene<LDS_SCENE>(sv, gblob, smem, blob_words);
     any_body<BVH, MODE, SPILL>(sv, bl, blob_words, smem, root, ra, rb, n_ptr, cap_in, heads, occluded, radiance);
 }
 
@@ -2569,7 +1465,7 @@ __global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH : PT_WAVES_GL
     const uint32_t need = max(fetch_plan(min(*a.fa.wn, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks, fetch_plan(min(*a.fa.ln, a.fa.cap_in), cdiv, (uint32_t)PT_TAPER).blocks);
     if (blockIdx.x >= need) return;
     uint32_t blob_words;
-    const Blob bl = stage_scene<LDS_SCENE, BVH == 2>(a.sv, a.gblob, smem, blob_words);
+    const Blob bl = stage_scene<LDS_SCENE>(a.sv, a.gblob, smem, blob_words);
     typedef const __attribute__((address_space(4))) FusedKArgs* FusedKArgsPtr;
     const FusedKArgsPtr k = (FusedKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     closest_body<BVH, CLOSEST_WORLD, SPILL>(a.sv, bl, blob_words, smem, a.fa.world_root, a.fa.wa, a.fa.wb, a.fa.wn, a.fa.cap_in, a.fa.wheads, &k->wout);
@@ -3301,14 +2197,6 @@ __global__ void k_material_probe(const SceneView sv, int material, uint32_t n, c
     o[8] = (float)(rng.k - draws);
 }
 
-static bool oct_nodes(const TraceLaunch& tl) { return PT_OCT_NODES != 0 && tl.lds_scene && (tl.scene.trav_flags & TRAV_OCT_NODES) != 0u; }
-size_t trace_lds_bytes(const TraceLaunch& tl, bool with_cands = false)
-{
-    // (k_closest2 / k_closest3 stage the plain blob: with_cands)
-    const size_t blob = tl.lds_scene ? tl.scene.blob_bytes + (oct_nodes(tl) && !with_cands ? (size_t)7 * tl.scene.n_nodes * sizeof(DNode) : 0) : 0;
-    return blob + (size_t)tl.scene.stack_lds * tl.block_threads * 8 + (with_cands ? (size_t)PT_CAND_SLOTS * tl.block_threads * 16 : 0);
-}
-
 } // namespace
 
 // ================================================================================================ launchers
@@ -3353,58 +2241,14 @@ static void launch_closest_impl(hipStream_t s, const TraceLaunch& tl, uint32_t r
     const bool spill = tl.scene.stack_entries > tl.scene.stack_lds;
     const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
-#define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, out)
-#if PT_TWO_PHASE
-    // closest hit with deferred leaves (k_closest2); it relies on nested boxes, which the host has checked (SceneView::trav_flags)
-    if constexpr (MODE != CLOSEST_LIGHTS)
-    {
-        if (tl.scene.trav_flags & TRAV_NESTED_BOXES)
-        {
-            const size_t lds = trace_lds_bytes(tl, true);
-            const bool ident = (tl.scene.trav_flags & TRAV_ALL_IDENTITY) != 0u;
-            const int sel = (tl.lds_scene ? 4 : 0) | (spill ? 2 : 0) | (ident ? 1 : 0);
-#if PT_TWO_PHASE == 2
-            const ClosestKArgs ka{tl.scene, blob, rq.a, rq.b, n_ptr, heads, root, cap_in, out};
-#define PT_LAUNCH3(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
-            switch (sel)
-            {
-            case 7: PT_LAUNCH3((k_closest3<true, MODE, true, true>)); break;
-            case 6: PT_LAUNCH3((k_closest3<true, MODE, true, false>)); break;
-            case 5: PT_LAUNCH3((k_closest3<true, MODE, false, true>)); break;
-            case 4: PT_LAUNCH3((k_closest3<true, MODE, false, false>)); break;
-            case 3: PT_LAUNCH3((k_closest3<false, MODE, true, true>)); break;
-            case 2: PT_LAUNCH3((k_closest3<false, MODE, true, false>)); break;
-            case 1: PT_LAUNCH3((k_closest3<false, MODE, false, true>)); break;
-            default: PT_LAUNCH3((k_closest3<false, MODE, false, false>)); break;
-            }
-#undef PT_LAUNCH3
-            return;
-#endif
-            switch (sel)
-            {
-            case 7: PT_LAUNCH((k_closest2<true, MODE, true, true>)); break;
-            case 6: PT_LAUNCH((k_closest2<true, MODE, true, false>)); break;
-            case 5: PT_LAUNCH((k_closest2<true, MODE, false, true>)); break;
-            case 4: PT_LAUNCH((k_closest2<true, MODE, false, false>)); break;
-            case 3: PT_LAUNCH((k_closest2<false, MODE, true, true>)); break;
-            case 2: PT_LAUNCH((k_closest2<false, MODE, true, false>)); break;
-            case 1: PT_LAUNCH((k_closest2<false, MODE, false, true>)); break;
-            default: PT_LAUNCH((k_closest2<false, MODE, false, false>)); break;
-            }
-            return;
-        }
-    }
-#endif
     const size_t lds = trace_lds_bytes(tl);
     const ClosestKArgs ka{tl.scene, blob, rq.a, rq.b, n_ptr, heads, root, cap_in, out};
 #define PT_LAUNCH1(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
-    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH1((k_closest<2, MODE, false>)); else PT_LAUNCH1((k_closest<2, MODE, true>)); } }
-    else if (tl.lds_scene && !spill) PT_LAUNCH1((k_closest<1, MODE, false>));
+    if (tl.lds_scene && !spill) PT_LAUNCH1((k_closest<1, MODE, false>));
     else if (tl.lds_scene) PT_LAUNCH1((k_closest<1, MODE, true>));
     else if (!spill) PT_LAUNCH1((k_closest<0, MODE, false>));
     else PT_LAUNCH1((k_closest<0, MODE, true>));
 #undef PT_LAUNCH1
-#undef PT_LAUNCH
 }
 template <int MODE>
 static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root, const RayQueue& rq, const uint32_t* n_ptr, uint32_t cap_in,
@@ -3415,8 +2259,7 @@ static void launch_any_impl(hipStream_t s, const TraceLaunch& tl, uint32_t root,
     const dim3 block(tl.block_threads);
     const uint4* blob = (const uint4*)tl.blob;
 #define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, tl.scene, blob, root, rq.a, rq.b, n_ptr, cap_in, heads, occluded, radiance)
-    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH((k_any<2, MODE, false>)); else PT_LAUNCH((k_any<2, MODE, true>)); } }
-    else if (tl.lds_scene && !spill) PT_LAUNCH((k_any<1, MODE, false>));
+    if (tl.lds_scene && !spill) PT_LAUNCH((k_any<1, MODE, false>));
     else if (tl.lds_scene) PT_LAUNCH((k_any<1, MODE, true>));
     else if (!spill) PT_LAUNCH((k_any<0, MODE, false>));
     else PT_LAUNCH((k_any<0, MODE, true>));
@@ -3502,8 +2345,7 @@ void launch_trace_fused(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
     const uint4* blob = (const uint4*)tl.blob;
     const FusedKArgs ka{tl.scene, blob, fa, wout, lout};
 #define PT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(resident_grid(K, tl, lds)), block, lds, s, ka)
-    if (PT_OCT_NODES != 0 && oct_nodes(tl)) { if constexpr (PT_OCT_NODES != 0) { if (!spill) PT_LAUNCH((k_trace_fused<2, false>)); else PT_LAUNCH((k_trace_fused<2, true>)); } }
-    else if (tl.lds_scene && !spill) PT_LAUNCH((k_trace_fused<1, false>));
+    if (tl.lds_scene && !spill) PT_LAUNCH((k_trace_fused<1, false>));
     else if (tl.lds_scene) PT_LAUNCH((k_trace_fused<1, true>));
     else if (!spill) PT_LAUNCH((k_trace_fused<0, false>));
     else PT_LAUNCH((k_trace_fused<0, true>));

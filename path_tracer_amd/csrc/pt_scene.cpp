@@ -812,22 +812,6 @@ int HostScene::flatten(std::string* err)
     // being traversed its TLAS leaf has been popped, leaving at most D_tlas - 1 TLAS entries underneath.
     const uint32_t tlas_depth = std::max(world.depth, lights.depth);
     f.stack_entries = std::max(tlas_depth, (tlas_depth > 0 ? tlas_depth - 1 : 0) + max_blas_depth);
-    // What k_closest2 relies on.  (i) Every child's box lies inside its parent's, bit for bit — the reference's builders take unions
-    // (surrounding_box, boundingbox.rs:134-139), so this holds by construction; it is checked, not assumed, because the deferred-leaf
-    // traversal's pop tests rest on it.  (ii) Whether every instance is the identity.
-    {
-        bool nested = true;
-        for (const DNode& d : f.nodes)
-        {
-            if ((d.link >> NODE_KIND_SHIFT) != NODE_BRANCH) continue;
-            const uint32_t l = d.link & NODE_PAYLOAD_MASK;
-            for (uint32_t c = l; c < l + 2u && c < f.nodes.size(); ++c)
-                for (int k = 0; k < 3; ++k) nested = nested && f.nodes[c].mn[k] >= d.mn[k] && f.nodes[c].mx[k] <= d.mx[k];
-        }
-        bool ident = !f.instances.empty();
-        for (const DInstance& in : f.instances) ident = ident && (in.qclass & INSTANCE_IDENTITY) != 0u;
-        f.trav_flags = (nested ? (uint32_t)TRAV_NESTED_BOXES : 0u) | (ident ? (uint32_t)TRAV_ALL_IDENTITY : 0u);
-    }
     flat = std::move(f);
     return 0;
 }

@@ -85,7 +85,6 @@ struct FlatScene
     uint32_t stack_entries = 0;
     float light_weight_sum = 0;
     bool has_volumes = false;
-    uint32_t trav_flags = 0;            // TRAV_* (pt_types.h): what the traversal kernels may assume about the trees
 };
 
 class HostScene

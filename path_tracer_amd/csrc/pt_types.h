@@ -125,26 +125,7 @@ struct SceneView
     uint32_t stack_entries;           // per-lane traversal stack capacity (exact bound)
     uint32_t stack_lds;               // closest-hit levels kept in LDS; deeper levels spill to `stack_spill` (deep BLASes only)
     uint64_t* stack_spill;            // 8-byte (node, t_enter) records [level - stack_lds][global lane], null when stack_entries <= stack_lds
-    uint32_t trav_flags;              // TRAV_*
 };
-// what the host found out about the trees (pt_scene.cpp: flatten)
-enum : uint32_t
-{
-    TRAV_ALL_IDENTITY = 1u, // every instance of both TLASes is the identity: one object-space image of a ray serves all of them
-    TRAV_NESTED_BOXES = 2u, // every child's box lies inside its parent's (bit for bit): box entry distances never decrease downwards
-    TRAV_OCT_NODES = 4u     // LDS-resident BVH small enough for eight direction-octant copies of its node array (set by the context, not the scene)
-};
-#ifndef PT_OCT_NODES
-#define PT_OCT_NODES 0      // 1: the experiment of stage_scene<.., OCT> (slower: LDS bandwidth; see there)
-#endif
-#ifndef PT_OCT_MAX_BYTES
-#define PT_OCT_MAX_BYTES (32u << 10) // most the eight copies + triangles + instances may take of a workgroup's LDS
-#endif
-// FIFO entries per lane of the closest-hit kernel with deferred leaves (k_closest2): 16 bytes each in LDS; power of two
-#ifndef PT_CAND_SLOTS
-#define PT_CAND_SLOTS 4
-#endif
-
 struct CameraView
 {
     float ray_matrix[16]; // (matrix * inv_projection), column-major                camera.rs:98

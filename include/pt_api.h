@@ -212,6 +212,9 @@ int pt_blas_dump(pt_ctx* ctx, int blas, uint32_t* n_nodes, uint32_t* root, float
                  uint32_t* n_prim_ids, uint32_t* prim_ids, uint32_t cap_nodes, uint32_t cap_ids);
 int pt_tlas_dump(pt_ctx* ctx, int which, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
                  uint32_t cap_nodes);
+/* the leaves' `matrix` / `inv_matrix` (tlas_bvh.rs:36-41; inv_matrix = matrix.inverse(), :99) in leaf allocation order — the index a
+ * leaf's `a` holds in pt_tlas_dump —, each as 12 floats, rows of the 3x4 */
+int pt_tlas_instances(pt_ctx* ctx, int which, uint32_t* n, float* matrix12, float* inv_matrix12, uint32_t cap);
 int pt_light_cdf(pt_ctx* ctx, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap);
 int pt_triangle_dump(pt_ctx* ctx, int blas, uint32_t prim, float out36[36]);
 

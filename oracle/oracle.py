@@ -74,6 +74,7 @@ def lib():
         L.pto_blas_count.argtypes = [C.c_void_p]
         L.pto_blas_dump.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_uint32, C.c_uint32]
         L.pto_tlas_dump.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_uint32]
+        L.pto_tlas_instances.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.pto_light_cdf.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_uint32]
         L.pto_triangle_dump.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.pto_ss_sobol_raw.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -269,6 +270,13 @@ class Oracle:
         assert r == 0, r
         n = nn.value
         return dict(root=root.value, boxes=boxes[:n].copy(), kind=kind[:n].copy(), a=a[:n].copy(), b=b[:n].copy())
+
+    def tlas_instances(self, which=0, cap=1 << 16):
+        n = C.c_uint32()
+        m = np.zeros((cap, 3, 4), np.float32); inv = np.zeros((cap, 3, 4), np.float32)
+        r = self.L.pto_tlas_instances(self.ctx, which, C.byref(n), _p(m), _p(inv), cap)
+        assert r == 0, r
+        return dict(matrix=m[:n.value].copy(), inv_matrix=inv[:n.value].copy())
 
     def light_cdf(self, cap=1 << 20):
         n = C.c_uint32(); mx = C.c_float()

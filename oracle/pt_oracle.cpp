@@ -1702,6 +1702,24 @@ int pto_tlas_dump(pto_ctx* c, int which, uint32_t* n_nodes, uint32_t* root, floa
     return tl.nodes.size() <= cap_nodes ? 0 : -1;
 }
 
+// TLASNodeType::Leaf { matrix, inv_matrix }  tlas_bvh.rs:36-41,92-101 — leaves in allocation order (their `instance` numbers)
+int pto_tlas_instances(pto_ctx* c, int which, uint32_t* n, float* matrix12, float* inv_matrix12, uint32_t cap)
+{
+    if (!c->scene) return -3;
+    const TLAS& tl = which ? c->scene->lights : c->scene->world;
+    uint32_t count = 0;
+    for (const TLASNode& nd : tl.nodes) count += nd.leaf ? 1u : 0u;
+    *n = count;
+    if (count > cap) return -1;
+    auto rows = [](const Affine& x, float* o) {
+        const float r[12] = {x.m.c0.x, x.m.c1.x, x.m.c2.x, x.t.x, x.m.c0.y, x.m.c1.y, x.m.c2.y, x.t.y, x.m.c0.z, x.m.c1.z, x.m.c2.z, x.t.z};
+        std::memcpy(o, r, sizeof(r));
+    };
+    for (const TLASNode& nd : tl.nodes)
+        if (nd.leaf && nd.instance < count) { rows(nd.matrix, matrix12 + 12 * (size_t)nd.instance); rows(nd.inv_matrix, inv_matrix12 + 12 * (size_t)nd.instance); }
+    return 0;
+}
+
 int pto_light_cdf(pto_ctx* c, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap)
 {
     if (!c->scene) return -3;

@@ -79,6 +79,7 @@ int pto_trace_any(pto_ctx*, int which, uint32_t n, const float* o, const float* 
 int pto_blas_count(pto_ctx*);
 int pto_blas_dump(pto_ctx*, int which, int blas, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a,
                   uint32_t* b, uint32_t* n_prim_ids, uint32_t* prim_ids, uint32_t cap_nodes, uint32_t cap_ids);
+int pto_tlas_instances(pto_ctx*, int which, uint32_t* n, float* matrix12, float* inv_matrix12, uint32_t cap);
 int pto_tlas_dump(pto_ctx*, int which, uint32_t* n_nodes, uint32_t* root, float* boxes6, uint32_t* kind, uint32_t* a, uint32_t* b,
                   uint32_t cap_nodes);
 int pto_light_cdf(pto_ctx*, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap);

@@ -31,7 +31,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_config", "pt_add_material", "pt_add_model", "pt_add_model_obj", "pt_model_vertices", "pt_build", "pt_set_camera",
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_read_frame", "pt_write_accumulation", "pt_render_samples", "pt_active_pixels", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
-    "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_light_cdf",
+    "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_tlas_instances", "pt_light_cdf",
     "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_step_stats",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
     "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl", "pt_multi_write_image",
@@ -155,6 +155,7 @@ def lib():
         L.pt_blas_count.argtypes = [vp]
         L.pt_blas_dump.argtypes = [vp, C.c_int] + [vp] * 8 + [u32, u32]
         L.pt_tlas_dump.argtypes = [vp, C.c_int] + [vp] * 6 + [u32]
+        L.pt_tlas_instances.argtypes = [vp, C.c_int, vp, vp, vp, u32]
         L.pt_light_cdf.argtypes = [vp] + [vp] * 6 + [u32]
         L.pt_triangle_dump.argtypes = [vp, C.c_int, u32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -485,6 +486,13 @@ class Renderer:
         self._chk(self.L.pt_tlas_dump(self.ctx, which, C.byref(nn), C.byref(root), _p(boxes), _p(kind), _p(a), _p(b), cap))
         n = nn.value
         return dict(root=root.value, boxes=boxes[:n].copy(), kind=kind[:n].copy(), a=a[:n].copy(), b=b[:n].copy())
+
+    def tlas_instances(self, which=0, cap=1 << 16):
+        """matrix / inv_matrix of every TLAS leaf (leaf allocation order), [n, 3, 4] each"""
+        n = C.c_uint32()
+        m = np.zeros((cap, 3, 4), np.float32); inv = np.zeros((cap, 3, 4), np.float32)
+        self._chk(self.L.pt_tlas_instances(self.ctx, which, C.byref(n), _p(m), _p(inv), cap))
+        return dict(matrix=m[:n.value].copy(), inv_matrix=inv[:n.value].copy())
 
     def light_cdf(self, cap=1 << 20):
         n = C.c_uint32(); mx = C.c_float()

@@ -1765,6 +1765,21 @@ int pt_tlas_dump(pt_ctx* c, int which, uint32_t* n_nodes, uint32_t* root, float*
     return PT_OK;
 }
 
+// TLASNodeType::Leaf { matrix, inv_matrix } (tlas_bvh.rs:36-41, 92-101) of every leaf, in arena order: rows of the two 3x4 matrices
+int pt_tlas_instances(pt_ctx* c, int which, uint32_t* n, float* matrix12, float* inv_matrix12, uint32_t cap)
+{
+    if (!c || !c->scene.built || !n) return PT_ERR_STATE;
+    const HostTlas& t = which ? c->scene.lights : c->scene.world;
+    *n = (uint32_t)t.instances.size();
+    if (t.instances.size() > cap || !matrix12 || !inv_matrix12) return PT_ERR_ARG;
+    auto rows = [](const xf34& x, float* o) {
+        const float r[12] = {x.m.c0.x, x.m.c1.x, x.m.c2.x, x.t.x, x.m.c0.y, x.m.c1.y, x.m.c2.y, x.t.y, x.m.c0.z, x.m.c1.z, x.m.c2.z, x.t.z};
+        std::memcpy(o, r, sizeof(r));
+    };
+    for (size_t i = 0; i < t.instances.size(); ++i) { rows(t.instances[i].fwd, matrix12 + 12 * i); rows(t.instances[i].inv, inv_matrix12 + 12 * i); }
+    return PT_OK;
+}
+
 int pt_light_cdf(pt_ctx* c, uint32_t* n, float* pdf, float* cdf, uint32_t* blas, uint32_t* prim, float* max_weight, uint32_t cap)
 {
     if (!c || !c->scene.built) return PT_ERR_STATE;

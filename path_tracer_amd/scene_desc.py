@@ -89,6 +89,66 @@ class Dielectric:
 IDENTITY_3x4 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], dtype=np.float32)
 
 
+# --------------------------------------------------------------------------------------------------------------------------------
+# Instance matrices the way the reference's host code builds them (src/main.rs:97-113): glam 0.23 quaternion -> Mat3A, all in binary32.
+# numpy float32 scalars round every + - * once (IEEE), so these are the bits glam's scalar formulas produce (recalled).
+
+# (sin, cos)(PI_f32 / 2) as binary32: what `Quat::from_rotation_y(std::f32::consts::PI)` holds in (y, w).  cos(1.57079637...) is not 0 in
+# binary32: the reference's own second dragon instance is therefore a GENERAL matrix with +-8.742278e-8 off the diagonal (main.rs:97).
+SIN_HALF_PI_F32 = np.float32(1.0)
+COS_HALF_PI_F32 = np.array([0xB33BBD2E], np.uint32).view(np.float32)[0]   # -4.37113883e-8
+
+
+def quat_from_rotation_y_pi() -> np.ndarray:
+    """glam::Quat::from_rotation_y(PI) = (0, sin(PI/2), 0, cos(PI/2)) in binary32 (main.rs:97)."""
+    return np.array([0.0, SIN_HALF_PI_F32, 0.0, COS_HALF_PI_F32], np.float32)
+
+
+def quat_unit(a, b, c, d) -> np.ndarray:
+    """The unit quaternion (a, b, c, d) / |(a, b, c, d)|, divided in binary64 (sqrt and / are correctly rounded on every host) and
+    rounded once to binary32 — test input data standing in for what `Quat::from_axis_angle(..)` / `.normalize()` would hand the
+    reference."""
+    q = np.array([a, b, c, d], np.float64)
+    return (q / np.sqrt((q * q).sum())).astype(np.float32)
+
+
+def mat3_from_quat(q) -> np.ndarray:
+    """glam Mat3A::from_quat in binary32; returns the 3x3 matrix (row-major array, columns are glam's x/y/z_axis)."""
+    f = np.float32
+    x, y, z, w = (f(v) for v in q)
+    x2, y2, z2 = x + x, y + y, z + z
+    xx, xy, xz, yy, yz, zz = x * x2, x * y2, x * z2, y * y2, y * z2, z * z2
+    wx, wy, wz = w * x2, w * y2, w * z2
+    one = f(1.0)
+    cols = [[one - (yy + zz), xy + wz, xz - wy], [xy - wz, one - (xx + zz), yz + wx], [xz + wy, yz - wx, one - (xx + yy)]]
+    return np.array(cols, np.float32).T.copy()
+
+
+def affine_from_rotation_translation(q, translation) -> np.ndarray:
+    """glam::Affine3A::from_rotation_translation(rotation, translation) as the C-ABI's row-major 3x4 (main.rs:112)."""
+    m = np.zeros((3, 4), np.float32)
+    m[:, :3] = mat3_from_quat(q)
+    m[:, 3] = np.asarray(translation, np.float32)
+    return m
+
+
+def is_rigid(m34) -> bool:
+    """Model::new's assert (model.rs:40-44): `to_scale_rotation_translation().0 == Vec3::ONE`, i.e. the three column lengths
+    sqrt((x*x + y*y) + z*z) are exactly 1.0f and the determinant is positive — in binary32, in glam's operation order."""
+    f = np.float32
+    m = np.asarray(m34, np.float32)
+    c = [m[:, k] for k in range(3)]
+
+    def dot(a, b):
+        return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+
+    def cross(a, b):
+        return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], np.float32)
+
+    det = dot(c[2], cross(c[0], c[1]))
+    return bool(det > 0 and all(np.sqrt(dot(v, v)) == f(1.0) for v in c))
+
+
 @dataclass
 class Model:
     """One BLAS: triangle soup + ONE material + rigid instance transforms (model.rs:26-52)."""

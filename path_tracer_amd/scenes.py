@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from .scene_desc import Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular, Volume
+from .scene_desc import (Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular, Volume, affine_from_rotation_translation, is_rigid,
+                         quat_from_rotation_y_pi, quat_unit)
 
 
 def _quad(a, b, c, d):
@@ -167,13 +168,14 @@ def cornell_mesh(width=256, height=256, level=6, material=None) -> SceneDesc:
 
 def cornell_spheres(width=256, height=256, level=4) -> SceneDesc:
     """configs[4] class: diffuse + dielectric + GGX-metal spheres (materials of main.rs:82-91) in the Cornell room, with an
-    instanced mirror sphere (exact 180-degree rotation) to exercise non-identity instance transforms."""
+    instanced mirror sphere turned by the reference's own `Quat::from_rotation_y(PI)` (main.rs:97: a GENERAL matrix in binary32, its
+    off-diagonal terms are +-8.742278e-8 because cos(PI_f32 / 2) is not 0) to exercise non-identity instance transforms."""
     room = cornell_models()[:4]
     s0 = sphere_mesh(level, (-150.0, -128.0, 60.0), 100.0)
     s1 = sphere_mesh(level, (40.0, -108.0, 130.0), 120.0)
     s2 = sphere_mesh(level, (140.0, -98.0, -120.0), 130.0)
     s3 = sphere_mesh(max(level - 1, 0), (-120.0, 180.0, -150.0), 60.0)
-    rot_y_pi = np.array([[[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0]]], dtype=np.float32)  # Quat::from_rotation_y(PI) of main.rs:97, exact
+    rot_y_pi = affine_from_rotation_translation(quat_from_rotation_y_pi(), (0.0, 0.0, 0.0))[None]   # main.rs:97,112 (translation 0 here)
     models = room + [
         _model(*s0, Lambertian.new((0.05, 0.05, 0.25)), "sphere_diffuse"),                       # main.rs:85
         _model(*s1, Dielectric.new((0.95, 0.95, 0.95), 1.5, None), "sphere_glass"),              # main.rs:89
@@ -182,6 +184,39 @@ def cornell_spheres(width=256, height=256, level=4) -> SceneDesc:
                   np.concatenate([np.eye(3, 4, dtype=np.float32)[None], rot_y_pi]), "sphere_mirror_x2"),
     ]
     return SceneDesc.new(models, reference_camera(width / height), "cornell_spheres")
+
+
+def rigid_from_quat(a, b, c, d, translation=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """from_rotation_translation(unit quaternion (a, b, c, d) / |..|, translation); the caller picks quaternions that pass model.rs:40-44"""
+    m = affine_from_rotation_translation(quat_unit(a, b, c, d), translation)
+    assert is_rigid(m), (a, b, c, d)
+    return m
+
+
+def cornell_instanced(width=256, height=256, level=2) -> SceneDesc:
+    """Instancing as the reference's own scene does it (main.rs:97-113: one model, `vec![IDENTITY, from_rotation_translation(
+    from_rotation_y(PI), (0, 200, 0))]`) and beyond: every non-room model is placed by GENERAL rigid matrices built glam's way
+    (unit quaternion -> Mat3A::from_quat in binary32, kept only if Model::new's scale == ONE assert passes), so every product in
+    Ray::transform (ray.rs:22-28), Affine3A::inverse (tlas_bvh.rs:99), the normal transform (tlas.rs:105) and the corner-only
+    AABB::transform (boundingbox.rs:51-57: TLAS leaf boxes that do NOT bound their rotated geometry) is inexact."""
+    room = cornell_models()[:4]
+    box_t, box_n = _box([(-40.0, 40.0), (-40.0, -40.0), (40.0, -40.0), (40.0, 40.0)], 60.0, -60.0)     # centred on the origin
+    ball = sphere_mesh(level, (0.0, 0.0, 0.0), 70.0)
+    slab_t, slab_n = _box([(-90.0, 25.0), (-90.0, -25.0), (90.0, -25.0), (90.0, 25.0)], 8.0, -8.0)
+    models = room + [
+        # the reference's own pair of instances, translation and all (main.rs:98,112), + two rotations about general axes
+        Model.new(box_t.astype(np.float32), box_n.astype(np.float32), Lambertian.new((0.73, 0.73, 0.73)),
+                  np.stack([np.array([[1, 0, 0, 150.0], [0, 1, 0, -168.0], [0, 0, 1, 40.0]], np.float32), reference_turn((-130.0, 32.0, -60.0)),
+                            rigid_from_quat(1, -7, -3, 2, (20.0, -140.0, 150.0)), rigid_from_quat(3, -1, 2, 4, (-150.0, -150.0, 120.0))]), "box_x4"),
+        # no identity instance at all: the BLAS is only ever seen through general matrices
+        Model.new(ball[0].astype(np.float32), ball[1].astype(np.float32), Dielectric.new((0.95, 0.95, 0.95), 1.5, None),
+                  np.stack([rigid_from_quat(1, -6, -5, 4, (-40.0, -150.0, -40.0)), rigid_from_quat(2, 3, -5, 7, (130.0, 60.0, -150.0))]), "glass_x2"),
+        Model.new(slab_t.astype(np.float32), slab_n.astype(np.float32), GGX.new_metal((0.9, 0.6, 0.2), 0.3),
+                  np.stack([rigid_from_quat(1, -7, 2, 3, (0.0, 120.0, -120.0)), reference_turn((0.0, 200.0, 0.0))]), "metal_slab_x2"),
+        Model.new(slab_t.astype(np.float32), slab_n.astype(np.float32), Specular.new((0.9, 0.95, 1.0)),
+                  rigid_from_quat(5, 1, 1, 7, (-160.0, 40.0, -200.0))[None], "mirror_slab"),
+    ]
+    return SceneDesc.new(models, reference_camera(width / height), "cornell_instanced")
 
 
 def cornell_media(width=256, height=256, level=3) -> SceneDesc:
@@ -202,10 +237,31 @@ def cornell_media(width=256, height=256, level=3) -> SceneDesc:
     return SceneDesc.new(models, reference_camera(width / height), "cornell_media")
 
 
-def random_scene(seed, width=48, height=32, with_media=True) -> SceneDesc:
+def general_turn(rng, spread=60) -> np.ndarray:
+    """A rigid instance matrix as the reference's host would build it — unit quaternion -> Mat3A::from_quat in binary32 (scene_desc) — that
+    passes Model::new's own `scale == ONE` assert (model.rs:40-44; about a third of random quaternions do: the three column lengths must
+    round to exactly 1.0f).  Every product of M3 * v is inexact: operation order in Ray::transform (ray.rs:22-28), Affine3A::inverse
+    (tlas_bvh.rs:99), the normal transform (tlas.rs:105) and the corner-only AABB::transform (boundingbox.rs:51-57) all show."""
+    while True:
+        q = rng.integers(-50, 51, 4)
+        if not q.any():
+            continue
+        m = affine_from_rotation_translation(quat_unit(*q), rng.integers(-spread, spread + 1, 3).astype(np.float32))
+        if is_rigid(m):
+            return m
+
+
+def reference_turn(translation=(0.0, 200.0, 0.0)) -> np.ndarray:
+    """The second dragon instance of the reference's own scene: from_rotation_translation(from_rotation_y(PI), (0, 200, 0))  main.rs:97-113."""
+    return affine_from_rotation_translation(quat_from_rotation_y_pi(), translation)
+
+
+def random_scene(seed, width=48, height=32, with_media=True, general=True) -> SceneDesc:
     """Seeded stress scene for parity fuzzing: several emissive models (multi-entry light CDF), triangle soups and spheres with
-    every material kind, nested/instanced transforms that are exact rigid motions (quarter turns + integer translations),
-    optional participating media.  Only numpy's IEEE + - * / sqrt and integer RNG output are used."""
+    every material kind, instanced rigid transforms — quarter turns + integer translations (exact) and, with `general`, glam-built
+    rotations about arbitrary axes (general_turn; at least one instance of every scene) and the reference's own from_rotation_y(PI) —
+    optional participating media.  Only numpy's IEEE + - * / sqrt and integer RNG output are used.  (general=False reproduces the
+    scenes of the round 1-3 fuzz campaigns seed for seed.)"""
     rng = np.random.default_rng(seed)
 
     def soup(n, centre, spread):
@@ -250,5 +306,12 @@ def random_scene(seed, width=48, height=32, with_media=True) -> SceneDesc:
         mats = None
         if rng.random() < 0.5:
             mats = np.stack([np.eye(3, 4, dtype=np.float32)] + [quarter_turn() for _ in range(int(rng.integers(1, 3)))])
+        if general and (k == 0 or rng.random() < 0.5):
+            # general rotations: object 0 always has one (sometimes WITHOUT an identity instance beside it), the others half the time
+            extra = [general_turn(rng) for _ in range(int(rng.integers(1, 3)))]
+            if rng.random() < 0.25:
+                extra.append(reference_turn(rng.integers(-60, 61, 3).astype(np.float32)))
+            base = [] if (mats is None and rng.random() < 0.5) else [np.eye(3, 4, dtype=np.float32)[None] if mats is None else mats]
+            mats = np.concatenate(base + [np.stack(extra)])
         models.append(Model.new(t.astype(np.float32), n.astype(np.float32), mat, mats, f"obj{k}"))
-    return SceneDesc.new(models, reference_camera(width / height), f"random_{seed}")
+    return SceneDesc.new(models, reference_camera(width / height), f"random_{seed}" + ("" if general else "_exact"))

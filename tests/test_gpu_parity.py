@@ -667,14 +667,17 @@ def test_gather_pad_and_deinterleave_run_on_device_tensors(api, cornell64):
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_scenes_bit_exact(api, oracle_mod, seed):
-    """fuzz: several lights, instanced quarter-turn transforms, every material kind, nested media"""
+    """fuzz: several lights, instanced transforms (quarter turns, glam-built rotations about general axes, the reference's own
+    from_rotation_y(PI)), every material kind, nested media"""
     from path_tracer_amd import scenes
     sc = scenes.random_scene(seed, 48, 32, with_media=(seed % 2 == 0))
+    assert any(np.count_nonzero(m[:, :3]) > 3 for mo in sc.models for m in mo.matrices)
     o = oracle_mod.Oracle(sc)
     r = api.Renderer(sc, 48, 32, max_bounces=10)
     _cmp_host = lambda a, b: all(np.array_equal(np.atleast_1d(np.asarray(a[k], np.float32 if isinstance(a[k], float) else None)).view(np.uint32),
                                                 np.atleast_1d(np.asarray(b[k], np.float32 if isinstance(b[k], float) else None)).view(np.uint32)) for k in a)
     assert _cmp_host(r.light_cdf(), o.light_cdf()) and _cmp_host(r.tlas_dump(0), o.tlas_dump(0)) and _cmp_host(r.tlas_dump(1), o.tlas_dump(1))
+    assert _cmp_host(r.tlas_instances(0), o.tlas_instances(0)) and _cmp_host(r.tlas_instances(1), o.tlas_instances(1))
     g = r.render_samples(0, 4)
     c = o.render_samples(48, 32, 4, max_bounces=10)
     assert_bit_equal(g, c, f"random scene {seed}")
@@ -686,3 +689,57 @@ def test_random_scenes_bit_exact(api, oracle_mod, seed):
     r.reset_stats(); r.reset_accumulation(); r.render(4, 3)
     st = r.stats()
     assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+
+
+def test_general_rigid_instances_bit_exact(api, oracle_mod):
+    """Every instance matrix of rounds 1-3 was a signed permutation: M3 * v had no inexact product, so no test could see a wrong operation
+    order in Ray::transform (ray.rs:22-28 -> to_object), Affine3A::inverse (tlas_bvh.rs:99), the normal transform (tlas.rs:105) or the
+    corner-only AABB::transform (boundingbox.rs:51-57).  scenes.cornell_instanced places its models by glam-built rotations about general
+    axes and by the reference's own from_rotation_translation(from_rotation_y(PI), (0, 200, 0)) (main.rs:97-113: +-8.742278e-8 off the
+    diagonal).  Kernels against the committed fixture (rays aimed at the instances, both TLASes, any-hit, per-sample radiance, position,
+    id, tallies), then against the live oracle on a larger frame."""
+    from path_tracer_amd import scenes
+    g = np.load(os.path.join(GOLD, "instanced.npz"))
+    W, H = 48, 32
+    sc = scenes.cornell_instanced(W, H)
+    r = api.Renderer(sc, W, H, max_bounces=7)
+    for which in (0, 1):
+        ti = r.tlas_instances(which)
+        assert_bit_equal(ti["matrix"], g[f"matrix{which}"], "matrix"); assert_bit_equal(ti["inv_matrix"], g[f"inv_matrix{which}"], "inv_matrix")
+        assert_bit_equal(r.tlas_dump(which)["boxes"], g[f"tlas{which}_boxes"], "TLAS boxes (corner-only AABB::transform)")
+        h = r.trace_closest(g["ray_o"], g["ray_d"], which=which)
+        for k in ("t", "u", "v", "inst", "prim"):
+            assert_bit_equal(h[k], g[f"hit{which}_{k}"], f"tlas{which} closest.{k}")
+    assert (np.isin(g["hit0_inst"], [6, 7, 8, 9, 10, 12]) & np.isfinite(g["hit0_t"])).sum() > 1000   # hits seen through general rotations
+    assert np.array_equal(r.trace_any(g["ray_o"], g["ray_d"], g["any_tmax"]), g["any_hit"])
+    assert_bit_equal(r.render_samples(0, 3), g["samples"], "per-sample radiance")
+    r.reset_stats(); r.reset_accumulation()
+    acc, pos, idb = r.render(0, 3)
+    assert_bit_equal(pos, g["position"], "first-hit position"); assert np.array_equal(idb, g["id"])
+    st = r.stats()
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest) == tuple(int(x) for x in g["counters"][:3])
+    # live oracle: a frame large enough for dynamic claims and striped tails, with the BVH read from global memory as well
+    W, H = 320, 200
+    sc = scenes.cornell_instanced(W, H, level=3)
+    o = oracle_mod.Oracle(sc)
+    want = o.render_samples(W, H, 2, max_bounces=9)
+    oacc, opos, oid, octr = o.render(W, H, 2, max_bounces=9)
+    for flags in (0, api.FLAG_NO_LDS_SCENE):
+        r = api.Renderer(sc, W, H, max_bounces=9, flags=flags)
+        assert_bit_equal(r.render_samples(0, 2), want, f"320x200 per-sample radiance (flags {flags})")
+        r.reset_stats(); r.reset_accumulation()
+        acc, pos, idb = r.render(0, 2)
+        assert_bit_equal(acc, oacc, "frame"); assert_bit_equal(pos, opos, "position"); assert np.array_equal(idb, oid)
+        st = r.stats()
+        assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+        rng = np.random.default_rng(21)
+        n = 20000
+        O = rng.uniform(-270, 270, (n, 3)).astype(np.float32); O[:, 1] += 50
+        D = rng.normal(size=(n, 3)); D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+        D[:200] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 200)] * rng.choice([-1.0, 1.0], (200, 1)).astype(np.float32)   # zero components: rotated, they stop being zero
+        for which in (0, 1):
+            a, b = r.trace_closest(O, D, which=which), o.trace_closest(O, D, which=which)
+            for k in ("inst", "prim", "t", "u", "v"):
+                assert_bit_equal(a[k], b[k], f"random rays tlas{which} closest.{k}")
+        tm = rng.uniform(0, 800, n).astype(np.float32)
+        assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))

@@ -404,3 +404,98 @@ def test_bench_configurations_name_real_scenes():
     assert bench.make_scene(bench.CONFIGS["cornell"]).n_triangles() == 36
     assert bench.make_scene(bench.CONFIGS["mesh82k"]).n_triangles() == 81932
     assert bench.make_scene(bench.CONFIGS["mixed"]).n_triangles() == 36
+
+
+def _world_triangles_f64(sc):
+    """every instance's triangles through its matrix in binary64: (vertices [n, 3, 3], (instance, primitive) tags)"""
+    tris, tag, inst = [], [], 0
+    for m in sc.models:
+        for M in m.matrices.astype(np.float64):
+            P = m.positions.astype(np.float64) @ M[:, :3].T + M[:, 3]
+            tris.append(P)
+            tag += [(inst, j) for j in range(len(P))]
+            inst += 1
+    return np.concatenate(tris), np.array(tag)
+
+
+def _closest_f64(ro, rd, T):
+    """Moller-Trumbore in binary64 over all triangles: an implementation that shares nothing with the oracle's Havel-Herout planes,
+    object-space rays or BVHs"""
+    e1, e2 = T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]
+    best = np.full(len(ro), np.inf); which = np.full(len(ro), -1)
+    for s in range(0, len(ro), 512):
+        o, d = ro[s:s + 512, None, :], rd[s:s + 512, None, :]
+        p = np.cross(d, e2[None]); det = (e1[None] * p).sum(-1)
+        inv = 1.0 / np.where(det == 0, 1e-300, det)
+        tv = o - T[None, :, 0]; u = (tv * p).sum(-1) * inv
+        q = np.cross(tv, e1[None]); v = (d * q).sum(-1) * inv; t = (e2[None] * q).sum(-1) * inv
+        t = np.where((u >= 0) & (v >= 0) & (u + v <= 1) & (t > 5e-4) & (np.abs(det) > 1e-12), t, np.inf)
+        j = t.argmin(1)
+        best[s:s + 512] = t[np.arange(len(j)), j]; which[s:s + 512] = j
+    return best, which
+
+
+def test_general_rigid_instances(api, oracle_mod):
+    """Instance matrices built the way glam builds them (unit quaternion -> Mat3A::from_quat in binary32) that pass Model::new's own
+    scale == ONE assert, the reference's own from_rotation_translation(from_rotation_y(PI), (0, 200, 0)) among them (main.rs:97-113):
+    every product of M3 * v is inexact, so operation order shows.  The library's and the oracle's independently written
+    Affine3A::inverse / AABB::transform agree with each other and with the committed fixture; the oracle's hits agree with a binary64
+    brute force over world-space triangles that shares none of its machinery; and where they differ it is quirk B-7 (corner-only
+    AABB::transform, boundingbox.rs:51-57: a rotated instance's TLAS box does not bound it), which both sides must reproduce."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import affine_from_rotation_translation, is_rigid, quat_from_rotation_y_pi
+    ref = affine_from_rotation_translation(quat_from_rotation_y_pi(), (0.0, 200.0, 0.0))
+    assert is_rigid(ref) and ref[0, 2] == np.float32(-8.742278e-08) and ref[2, 0] == np.float32(8.742278e-08) and ref[0, 0] == -1.0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "instanced.npz"))
+    sc = scenes.cornell_instanced(48, 32)
+    assert any(np.array_equal(m, ref) for mo in sc.models for m in mo.matrices)
+    assert sum(int(np.count_nonzero(m[:, :3]) == 9) for mo in sc.models for m in mo.matrices) >= 6     # rotations about general axes
+    r = api.Renderer(sc, 48, 32)
+    o = oracle_mod.Oracle(sc)
+    for which in (0, 1):
+        a, b = r.tlas_instances(which), o.tlas_instances(which)
+        for k in ("matrix", "inv_matrix"):
+            assert_bit_equal(a[k], b[k], f"tlas{which}.{k} library vs oracle")
+            assert_bit_equal(b[k], g[f"{k}{which}"], f"tlas{which}.{k} oracle vs fixture")
+        _cmp(r.tlas_dump(which), o.tlas_dump(which), f"tlas{which}")
+        assert_bit_equal(o.tlas_dump(which)["boxes"], g[f"tlas{which}_boxes"], "TLAS boxes vs fixture")
+        # Affine3A::inverse really inverts (binary64 product within binary32 rounding of the identity)
+        M = np.concatenate([b["matrix"].astype(np.float64), np.tile([0, 0, 0, 1.0], (len(b["matrix"]), 1, 1))], axis=1)
+        Mi = np.concatenate([b["inv_matrix"].astype(np.float64), np.tile([0, 0, 0, 1.0], (len(b["matrix"]), 1, 1))], axis=1)
+        assert np.abs(Mi @ M - np.eye(4)).max() < 1e-4
+    # the oracle still reproduces the fixture's hits (regression pin) ...
+    ro, rd = g["ray_o"], g["ray_d"]
+    h = o.trace_closest(ro, rd)
+    for k in ("t", "u", "v", "inst", "prim", "normal", "front"):
+        assert_bit_equal(h[k], g["hit0_" + k], f"closest.{k}")
+    assert np.array_equal(o.trace_any(ro, rd, g["any_tmax"]), g["any_hit"])
+    # ... and they are the hits of the transformed geometry
+    T, tag = _world_triangles_f64(sc)
+    bt, bi = _closest_f64(ro.astype(np.float64), rd.astype(np.float64), T)
+    hit = np.isfinite(h["t"])
+    same = hit & (tag[bi, 0] == h["inst"]) & (tag[bi, 1] == h["prim"])
+    general = np.isin(h["inst"], [6, 7, 8, 9, 10, 12])
+    ht = np.where(hit, h["t"], np.inf).astype(np.float64)
+    assert (same & general).sum() > 500 and np.abs(bt[same] - ht[same]).max() < 2e-3
+    # world-space normal = matrix * (interpolated object normal)  tlas.rs:105: compare with R * n computed in binary64
+    tri_n = np.concatenate([mo.normals.astype(np.float64) @ M[:, :3].astype(np.float64).T for mo in sc.models for M in mo.matrices])
+    u, v = h["u"].astype(np.float64)[same], h["v"].astype(np.float64)[same]
+    nn = tri_n[bi[same]]
+    n64 = nn[:, 0] * (1 - u - v)[:, None] + nn[:, 1] * u[:, None] + nn[:, 2] * v[:, None]
+    n64 /= np.linalg.norm(n64, axis=1, keepdims=True)
+    n64 *= np.where((n64 * rd[same]).sum(1) < 0, 1.0, -1.0)[:, None]           # face_forward (primitive.rs:166-169)
+    assert np.abs(n64 - h["normal"][same]).max() < 1e-4
+    # where the oracle's hit is NOT the binary64 closest one it is farther (geometry missed, never invented), the missed triangle
+    # belongs to an instance rotated about a general axis, and the ray misses that instance's corner-only TLAS box
+    other = np.isfinite(bt) & ~same
+    other[other] = ~(np.abs(bt[other] - ht[other]) <= 1e-2)
+    assert other.sum() > 100 and (bt[other] < ht[other]).all()
+    assert np.isin(tag[bi[other], 0], [6, 7, 8, 9, 10, 12]).all()
+    td = o.tlas_dump(0)
+    leaf_box = {int(a): td["boxes"][i].astype(np.float64) for i, (k, a) in enumerate(zip(td["kind"], td["a"])) if k == 1}
+    o64, d64 = ro.astype(np.float64)[other], rd.astype(np.float64)[other]
+    boxes = np.stack([leaf_box[int(i)] for i in tag[bi[other], 0]])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (boxes[:, :3] - o64) / d64, (boxes[:, 3:] - o64) / d64
+    enter, leave = np.fmax(np.fmin(t0, t1).max(1), 5e-4), np.fmax(t0, t1).min(1)
+    assert (enter > np.minimum(leave, bt[other] + 1.0)).mean() > 0.97, "the missed triangles lie outside the boxes the reference gives their instances"

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the wavefront integrator, one JSON line per run (contract in the task description).
 
-    python bench.py [--config cornell|mesh82k|mesh328k|mixed|spheres] [--gpus N] [--steps K] [--warmup W] [--spp S]
+    python bench.py [--config cornell|mesh82k|atrium|mesh328k|mixed|spheres] [--gpus N] [--steps K] [--warmup W] [--spp S]
 
 Default: BASELINE.json configs[1], the configuration the metric is quoted on — the Cornell-class scene at 1920x1080, 256 spp,
 depth 8; one "step" = one complete render of the frame with the scene already resident in HBM.  The other names are the other
 BASELINE.json configurations (parity-test cases, selectable here so that every number in DESIGN.md has a one-line command):
     mesh82k   configs[2]  81 932 triangles (displaced icosphere in the Cornell room), 1920x1080, 512 spp, depth 8
-    mesh328k  configs[3]  327 692 triangles, 1920x1080, 1024 spp, depth 8
+    atrium    configs[3]  the instanced atrium SURVEY 8(d) fixes for it: 293 BLASes, ~590 TLAS leaves, ~250 k instanced triangles, 1920x1080, 1024 spp, depth 8
+    mesh328k  configs[3]  (class stand-in of rounds 1-3) 327 692 triangles in ONE displaced icosphere, 1920x1080, 1024 spp, depth 8
     mixed     configs[4]  diffuse + dielectric + GGX metal Cornell boxes, 4096x4096, 4096 spp, depth 16 (hundreds of batches on two pipelines)
     spheres   configs[4]  three 5 120-triangle spheres + an instanced mirror sphere, 4096x4096, depth 16; 1024 of the 4096 spp by default (~60 s rule)
 N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: rows are dealt to ranks in strips (no
@@ -28,15 +29,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_CLOSEST_RAY = 48      # 32 B ray in + 16 B hit out; + 32 B per node visited + 48 B per triangle tested when the BVH is not LDS-resident
-PROFILE_ROUND = "r03"           # profiles/<round>_<config>_traffic.json: the committed rocprofv3 PMC passes the counter-derived fields come from
+PROFILE_ROUND = "r04"           # profiles/<round>_<config>_traffic.json: the committed rocprofv3 PMC passes the counter-derived fields come from
 
-# name -> scene function, keyword arguments, width, height, the configuration's own spp, spp of a default run, depth, workload description
+# name -> scene function, keyword arguments, width, height, the configuration's own spp, spp of a default run, depth, workload description,
+#         spp of the CPU baseline's FIXED sample (the whole frame at that many samples: the same work on every box and in every round)
 CONFIGS = {
-    "cornell": ("cornell_box", {}, 1920, 1080, 256, 256, 8, "Cornell box (36 triangles, 6 BLAS)"),
-    "mesh82k": ("cornell_mesh", {"level": 6}, 1920, 1080, 512, 512, 8, "Cornell room + 81 920-triangle displaced icosphere (BASELINE configs[2] class)"),
-    "mesh328k": ("cornell_mesh", {"level": 7}, 1920, 1080, 1024, 1024, 8, "Cornell room + 327 680-triangle displaced icosphere (BASELINE configs[3] class)"),
-    "mixed": ("cornell_mixed", {}, 4096, 4096, 4096, 4096, 16, "Cornell box, tall box GGX metal, short box dielectric (BASELINE configs[4])"),
-    "spheres": ("cornell_spheres", {}, 4096, 4096, 4096, 1024, 16, "Cornell room + diffuse / glass / GGX spheres + instanced mirror sphere (BASELINE configs[4] class)"),
+    "cornell": ("cornell_box", {}, 1920, 1080, 256, 256, 8, "Cornell box (36 triangles, 6 BLAS)", 64),
+    "mesh82k": ("cornell_mesh", {"level": 6}, 1920, 1080, 512, 512, 8, "Cornell room + 81 920-triangle displaced icosphere (BASELINE configs[2] class)", 16),
+    "atrium": ("atrium", {}, 1920, 1080, 1024, 1024, 8, "instanced atrium: 293 BLASes, ~590 TLAS leaves, ~250 k instanced triangles (BASELINE configs[3] as SURVEY 8d defines it)", 8),
+    "mesh328k": ("cornell_mesh", {"level": 7}, 1920, 1080, 1024, 1024, 8, "Cornell room + 327 680-triangle displaced icosphere (BASELINE configs[3] class)", 8),
+    "mixed": ("cornell_mixed", {}, 4096, 4096, 4096, 4096, 16, "Cornell box, tall box GGX metal, short box dielectric (BASELINE configs[4])", 8),
+    "spheres": ("cornell_spheres", {}, 4096, 4096, 4096, 1024, 16, "Cornell room + diffuse / glass / GGX spheres + instanced mirror sphere (BASELINE configs[4] class)", 4),
 }
 
 
@@ -46,28 +49,24 @@ def make_scene(cfg):
     return getattr(scenes, fn)(w, h, **kw)
 
 
-def cpu_baseline(cfg, depth, n_sobol, seconds_budget=20.0):
-    """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this host's cores on a bounded sample of the
-    same workload: the full frame, as many spp as fit the budget (>= 1).  Its counters 6 and 7 (BVH nodes visited / triangles tested
-    by the world closest-hit casts, on rays statistically identical to the timed ones) give SURVEY 8(d)'s algorithmic bytes per ray."""
+def cpu_baseline(cfg, depth, n_sobol):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this host's cores on a FIXED, bounded sample of the
+    same workload: the whole frame at CONFIGS[..][8] samples per pixel (Cornell: 64 of the 256 spp, ~10 s on the GPU box's host) — the
+    same rays in every round and on every box, so the number is comparable (rounds 1-3 filled a time budget: 96 / 107 / 170 spp).  Its
+    counters 6 and 7 (BVH nodes visited / triangles tested by the world closest-hit casts, on rays statistically identical to the timed
+    ones) give SURVEY 8(d)'s algorithmic bytes per ray."""
     from oracle import oracle as O
-    w, h, spp_full = cfg[2], cfg[3], cfg[4]
+    w, h, spp_full, spp = cfg[2], cfg[3], cfg[4], cfg[8]
     o = O.Oracle(make_scene(cfg))
     threads = max(1, (os.cpu_count() or 2) - 1)          # num_cpus::get() - 1, src/main.rs:72
+    o.render(w, h, 1, first_sample=spp, max_bounces=depth, n_sobol=n_sobol, threads=threads)   # page the scene in, start the pool; not timed
     t0 = time.perf_counter()
-    _, _, _, ctr = o.render(w, h, 1, max_bounces=depth, n_sobol=n_sobol, threads=threads)
+    _, _, _, ctr = o.render(w, h, spp, max_bounces=depth, n_sobol=n_sobol, threads=threads)
     dt = time.perf_counter() - t0
-    spp = 1
-    extra = int(min(spp_full - 1, max(0, (seconds_budget - dt) // max(dt, 1e-3))))
-    if extra >= 1:
-        t0 = time.perf_counter()
-        _, _, _, ctr = o.render(w, h, extra, first_sample=1, max_bounces=depth, n_sobol=n_sobol, threads=threads)
-        dt = time.perf_counter() - t0
-        spp = extra
     rays = int(ctr[0] + ctr[1] + ctr[2])
     closest = max(int(ctr[0]), 1)
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-            "sample": f"{cfg[7]} {w}x{h}, {spp} spp of {spp_full}, depth {depth}, {threads} threads, {dt:.1f} s; rays = casts at the reference's call sites "
+            "sample": f"{cfg[7]} {w}x{h}, samples 0..{spp - 1} of {spp_full} (fixed), depth {depth}, {threads} threads, {dt:.1f} s; rays = casts at the reference's call sites "
                       f"(compare with config.cast_Mray_per_s)",
             "nodes_visited_per_closest_ray": int(ctr[6]) / closest, "triangles_tested_per_closest_ray": int(ctr[7]) / closest}
 
@@ -176,13 +175,22 @@ def main():
         rays, paths, traversed = float(st.rays), float(st.paths), float(traversed_local)
 
     kernel_ms = None
-    s2 = None
+    s1 = None
     if rank == 0 and world == 1 and not args.no_kernel_ms:
-        # every kernel category timed, in a SECOND, untimed step (HIP events around every launch serialise the side stream and add
-        # idle time, so they stay out of the timed region); long workloads time a 1/16 sample of the spp
-        r.set_config(flags=api.FLAG_TIMING_ALL, pipelines=1)   # one batch at a time: with two pipelines an event pair also spans the other pipeline's kernels
-        r.reset_stats()
         spp_k = spp if not big else max(1, spp // 16)
+        # (a) the dominant kernel's launch durations: one extra, untimed render of the SAME launch structure as the timed steps (the fused
+        # world + NEE launch on LDS scenes) with its batches one after another on ONE pipeline — with two pipelines an event pair on one
+        # launch stream also spans the other pipeline's kernels.  This is what `rocprofv3 --kernel-trace` of `bench.py --pipelines 1` sees.
+        r.set_config(flags=api.FLAG_TIMING, pipelines=1)
+        r.reset_stats()
+        r.reset_accumulation()
+        r.render_device(0, spp_k)
+        torch.cuda.synchronize(dev)
+        s1 = r.stats()
+        # (b) every kernel category timed, in another untimed render (HIP events around every launch serialise the side stream and add
+        # idle time, and the world and NEE launches of a bounce are then separate launches); long workloads time a 1/16 sample of the spp
+        r.set_config(flags=api.FLAG_TIMING_ALL, pipelines=1)
+        r.reset_stats()
         r.reset_accumulation()
         r.render_device(0, spp_k)
         torch.cuda.synchronize(dev)
@@ -190,8 +198,8 @@ def main():
         f = spp / spp_k
         kernel_ms = {"trace_closest": s2.ms_trace_closest * f, "trace_any": s2.ms_trace_any * f, "trace_light": s2.ms_trace_light * f, "shade": s2.ms_shade * f,
                      "generate": s2.ms_generate * f, "accumulate": s2.ms_accumulate * f,
-                     "source": "one extra untimed render with HIP events around every launch (PT_FLAG_TIMING_ALL), batches one after another on one pipeline "
-                               "(the timed steps overlap the batches of two pipelines, so these can add up to more than ms_per_step); per step"
+                     "source": "one extra untimed render with HIP events around every launch (PT_FLAG_TIMING_ALL; world and NEE launches separate), batches one after another on "
+                               "one pipeline (the timed steps overlap the batches of two pipelines, so these can add up to more than ms_per_step); per step"
                                + ("" if spp_k == spp else f", measured on {spp_k} spp and scaled to {spp}")}
 
     if rank == 0:
@@ -201,17 +209,19 @@ def main():
         # TWO pipelines (requests that do not fit at once; BVHs in global memory), an event pair also spans the other pipeline's kernels, so the
         # one-pipeline render behind kernel_ms (events around every launch, nothing else on the device) is the clean measurement and is used
         # when it exists; on one pipeline (the headline) the two agree.
-        if s2 is not None and s2.launches_trace_closest:
-            avg_ms = s2.ms_trace_closest / s2.launches_trace_closest
-            rays_per_launch_meas = (s2.rays_closest - s2.rays_primary_culled) / s2.launches_trace_closest
-            launch_src = "events around every launch of the extra one-pipeline render (kernel_ms)"
+        if s1 is not None and s1.launches_trace_closest:
+            avg_ms = s1.ms_trace_closest / s1.launches_trace_closest
+            rays_per_launch_meas = (s1.rays_closest - s1.rays_primary_culled) / s1.launches_trace_closest
+            launches_meas = int(s1.launches_trace_closest)
+            launch_src = "HIP events on the launch stream around the world closest-hit launches of one extra render on ONE pipeline (same launch structure as the timed steps)"
         else:
             avg_ms = avg_ms_timed
             rays_per_launch_meas = None
-            launch_src = "events on the launch stream in the timed region"
+            launches_meas = int(launches)
+            launch_src = "HIP events on the launch stream in the timed region"
         lds_scene = bool(st.lds_scene)
         out = {
-            "metric": "Mray/s at 1920x1080, 256 spp; achieved HBM GB/s in traversal kernel",
+            "metric": f"Mray/s at {width}x{height}, {spp} spp; achieved HBM GB/s in traversal kernel",
             "value": traversed / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
@@ -254,18 +264,22 @@ def main():
         waves = kc.get("waves_per_simd")
         va, lanes = kc.get("valu_active_frac"), kc.get("lanes_per_valu_instr")
         valu_busy = va * waves if (va is not None and waves) else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        binding = "valu-issue" if lds_scene else "valu-issue at low lane agreement, then L2 latency"
+        roof = {"bound": binding, "axis": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": ("k_closest<LDS, PRIMARY> (bounce 0) + k_trace_fused<LDS> (later bounces: the world closest-hit rays, then the few BSDF-sampled NEE rays of the bounce before)"
-                           if lds_scene else "k_closest<global BVH, PRIMARY|WORLD>"), "avg_launch_ms": avg_ms, "avg_launch_ms_timed_region": avg_ms_timed, "launch_time_source": launch_src, "launches": int(launches),
+                           if lds_scene else "k_closest<global BVH, PRIMARY> (bounce 0) + k_closest<global BVH, WORLD> (later bounces)"),
+                "avg_launch_ms": avg_ms, "launches": launches_meas, "launch_time_source": launch_src,
+                "avg_launch_ms_timed_region": avg_ms_timed, "launches_timed_region": int(launches),
                 "algorithmic_bytes_per_ray": alg_per_ray, "algorithmic_bytes_source": alg_src, "rays_per_launch": rays_per_launch,
                 "closest_Mray_per_s_in_kernel": rays_per_launch / max(avg_ms, 1e-9) / 1e3,
                 # what actually binds the kernel (profiles/r03_*_summary.md): VALU issue.  valu_busy = share of the SIMD's issue cycles that carry a VALU
                 # instruction (VALU-active share of a wave's lifetime x resident waves per SIMD); effective_valu_frac = valu_busy x lanes / 64
-                "binding_resource": "valu-issue" if lds_scene else "valu-issue at low lane agreement, then L2 latency",
+                "binding_resource": binding,
                 "valu_active_frac": va, "waves_per_simd": waves, "lanes_per_valu_instr": lanes, "valu_busy": valu_busy,
                 "effective_valu_frac": (valu_busy * lanes / 64.0) if (valu_busy is not None and lanes) else None,
-                "note": "`achieved`/`frac` are SURVEY 8(d)'s ALGORITHMIC bytes over the launch time on the HBM roofline, not bandwidth in use: the kernel is bound by VALU issue "
-                        "(binding_resource); counter traffic is `traffic` per launch, `counter_GBps` per second, `counter_over_algorithmic` their ratio"}
+                "note": "`bound` names what binds the kernel (counters: profiles/); `achieved`/`peak`/`frac` are SURVEY 8(d)'s ALGORITHMIC bytes per launch "
+                        "(`algorithmic_bytes_per_ray` x `rays_per_launch`) over `avg_launch_ms` on the HBM axis (`axis`), not bandwidth in use; `launches` x `rays_per_launch` "
+                        "are the extra render's own; counter traffic is `traffic` per launch, `counter_GBps` per second, `counter_over_algorithmic` their ratio"}
         if kc.get("hbm_bytes_per_ray") is not None:
             roof["traffic"] = kc["hbm_bytes_per_ray"] * rays_per_launch
             roof["counter_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None

@@ -202,7 +202,14 @@ public:
         return f;
     }
     // checkpoint / resume: put a frame's state (as frame() / pt_render returned it) back, e.g. in another process
-    void write_accumulation(const Frame& f) { check(pt_write_accumulation(ctx_, f.data.data(), f.position.empty() ? nullptr : f.position.data(), f.id.empty() ? nullptr : f.id.data())); }
+    void write_accumulation(const Frame& f)
+    {
+        // pt_write_accumulation copies width * height texels from each pointer: a frame saved at another size must not be read past its end
+        const size_t px = (size_t)width_ * height_;
+        if (f.data.size() != px * 4 || (!f.position.empty() && f.position.size() != px * 4) || (!f.id.empty() && f.id.size() != px))
+            throw Error(PT_ERR_ARG, "write_accumulation: the frame was not saved at this renderer's " + std::to_string(width_) + "x" + std::to_string(height_));
+        check(pt_write_accumulation(ctx_, f.data.data(), f.position.empty() ? nullptr : f.position.data(), f.id.empty() ? nullptr : f.id.data()));
+    }
     std::vector<float> present() const { std::vector<float> v((size_t)width_ * height_ * 4); check(pt_present(ctx_, v.data())); return v; }
     std::vector<uint8_t> present_rgb8() const { std::vector<uint8_t> v((size_t)width_ * height_ * 3); check(pt_present_rgb8(ctx_, v.data())); return v; }
     void write_image(const std::string& path) const { check(pt_write_image(ctx_, path.c_str())); }

@@ -350,6 +350,9 @@ class Renderer:
         data = np.ascontiguousarray(data, np.float32)
         pos = None if position is None else np.ascontiguousarray(position, np.float32)
         idb = None if ident is None else np.ascontiguousarray(ident, np.uint32)
+        px = self.cfg.width * self.cfg.height      # the library copies width * height texels from each pointer
+        if data.size != px * 4 or (pos is not None and pos.size != px * 4) or (idb is not None and idb.size != px):
+            raise PtError(-1, f"write_accumulation: arrays are not those of a {self.cfg.width}x{self.cfg.height} frame")
         self._chk(self.L.pt_write_accumulation(self.ctx, _p(data), None if pos is None else _p(pos), None if idb is None else _p(idb)))
 
     def accum_device_ptr(self):

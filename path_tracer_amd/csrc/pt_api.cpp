@@ -587,7 +587,11 @@ int harvest_batch(pt_ctx* c, int pipe)
     for (uint32_t r = 0; r < rows; ++r)
         // a producer that found a queue full has diverted its entries to the queue's dump area (nothing was written out of bounds)
         // and raised this flag: the batch's results are incomplete
-        if (pp.h_counters[r].overflow) return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
+        if (pp.h_counters[r].overflow)
+        {
+            pp.ev_used = 0; // the abandoned batch's event pairs must not be added to the next render's timers
+            return fail(c, PT_ERR_LIMIT, "a wavefront queue was full (pt_config.queue_slack too small for this scene); the batch was abandoned, no memory was overwritten");
+        }
     // exact tallies live beside the claim cursors, one per cursor line (64 addresses per queue instead of one: a launch of a few
     // thousand waves that each add to ONE word spends ~50 us on that alone)
     for (uint32_t r = 0; r < rows; ++r)
@@ -1019,6 +1023,7 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
             (void)hipStreamSynchronize(c->pipe_stream(i));
             if (c->pipe[i].side_stream) (void)hipStreamSynchronize(c->pipe[i].side_stream);
             c->pipe[i].busy = false;
+            c->pipe[i].ev_used = 0; // (batches that were never harvested: their timers are void as well)
         }
         (void)hipGetLastError();
         if (c->d_accum.p) (void)hipMemsetAsync(c->d_accum.p, 0, c->d_accum.bytes, c->stream);

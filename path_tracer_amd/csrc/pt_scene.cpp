@@ -100,6 +100,8 @@ void parallel_slices(size_t n, F fn)
     if (t <= 1) { fn((size_t)0, n); return; }
     std::vector<std::thread> pool;
     std::vector<std::exception_ptr> failed(t);
+    pool.reserve(t);                                   // before any thread exists: emplace_back below never reallocates (a bad_alloc there would
+                                                       // unwind past joinable threads and terminate)
     size_t started = 1;
     try
     {
@@ -109,7 +111,7 @@ void parallel_slices(size_t n, F fn)
                 catch (...) { failed[started] = std::current_exception(); }              // handed to the caller after the join
             });
     }
-    catch (const std::system_error&) {}                                                  // fewer threads than asked for: the caller does the rest
+    catch (...) {}                                     // fewer threads than asked for (std::system_error, or no memory for one): the caller does the rest
     try
     {
         fn((size_t)0, n / t);

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .scene_desc import (Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular, Volume, affine_from_rotation_translation, is_rigid,
+from .scene_desc import (IDENTITY_3x4, Camera, Dielectric, Emissive, GGX, Lambertian, Model, SceneDesc, Specular, Volume, affine_from_rotation_translation, is_rigid,
                          quat_from_rotation_y_pi, quat_unit)
 
 
@@ -315,3 +315,172 @@ def random_scene(seed, width=48, height=32, with_media=True, general=True) -> Sc
             mats = np.concatenate(base + [np.stack(extra)])
         models.append(Model.new(t.astype(np.float32), n.astype(np.float32), mat, mats, f"obj{k}"))
     return SceneDesc.new(models, reference_camera(width / height), f"random_{seed}" + ("" if general else "_exact"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] as SURVEY.md 8(d) fixes it: a procedurally generated ~250 k-triangle ATRIUM (columns / arches grid) —
+# what makes a Sponza-class scene different from one big mesh is many objects, heavy instancing, occlusion and a deep TLAS.
+
+def _circle(k):
+    """4 * 2^k points on the unit circle, counter-clockwise from (1, 0), by repeated normalised midpoints (sqrt only: host-independent)."""
+    p = np.array([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0], [0.0, -1.0]])
+    for _ in range(k):
+        mid = p + np.roll(p, -1, axis=0)
+        mid /= np.sqrt((mid * mid).sum(1, keepdims=True))
+        q = np.empty((2 * len(p), 2))
+        q[0::2], q[1::2] = p, mid
+        p = q
+    return p
+
+
+def _grid_mesh(P):
+    """triangles of a [rows, cols, 3] vertex grid that is closed around its columns (cols wraps), smooth vertex normals"""
+    rows, cols, _ = P.shape
+    idx = np.arange(rows * cols).reshape(rows, cols)
+    a, b = idx[:-1], idx[1:]
+    an, bn = np.roll(a, -1, axis=1), np.roll(b, -1, axis=1)
+    f = np.concatenate([np.stack([a, an, bn], -1).reshape(-1, 3), np.stack([a, bn, b], -1).reshape(-1, 3)])
+    v = P.reshape(-1, 3)
+    tris = v[f]
+    fn = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, f[:, k], fn)
+    vn /= np.sqrt((vn * vn).sum(1, keepdims=True))
+    return tris, vn[f] + 0.0
+
+
+def _column(variant, height=520.0, k=2, rings=48):
+    """a fluted column standing on y = 0, axis = the y axis: (4 * 2^k) segments x `rings` rings, capped; four profile variants"""
+    c = _circle(k)
+    seg = len(c)
+    # radius profile along the height (fractions of the height -> radius), piecewise linear: plinth, shaft with entasis, capital
+    prof = [(0.0, 46.0), (0.04, 46.0), (0.05, 36.0), (0.5, 33.0 + 2.0 * variant), (0.9, 28.0), (0.93, 40.0), (1.0, 44.0 + 3.0 * (variant % 2))]
+    t = np.arange(rings + 1) / float(rings)
+    ys, rs = np.array([p[0] for p in prof]), np.array([p[1] for p in prof])
+    j = np.clip(np.searchsorted(ys, t, side="right") - 1, 0, len(ys) - 2)
+    r = rs[j] + (rs[j + 1] - rs[j]) * ((t - ys[j]) / (ys[j + 1] - ys[j]))
+    flute = 1.0 - (0.05 + 0.01 * variant) * (np.arange(seg) % 2)              # every other meridian lies deeper: flutes
+    shaft = ((t > 0.05) & (t < 0.9)).astype(np.float64)
+    R = r[:, None] * (1.0 - (1.0 - flute[None, :]) * shaft[:, None])
+    P = np.stack([R * c[None, :, 0], np.broadcast_to((t * height)[:, None], R.shape), R * c[None, :, 1]], -1)
+    tris, nrm = _grid_mesh(P)
+    top = np.array([0.0, height, 0.0])
+    cap = np.stack([np.broadcast_to(top, (seg, 3)), P[-1], np.roll(P[-1], -1, axis=0)], 1)
+    cap_n = np.broadcast_to(np.array([0.0, 1.0, 0.0]), cap.shape)
+    return np.concatenate([tris, cap]), np.concatenate([nrm, cap_n]) + 0.0
+
+
+def _arch(span=300.0, k=3, depth=50.0, thick=34.0):
+    """a semicircular arch in the x-y plane, springing from (-span/2, 0) and (span/2, 0), extruded along z by `depth`: intrados,
+    extrados and the two faces; flat normals"""
+    c = _circle(k)
+    half = c[: len(c) // 2 + 1]                                                    # angle 0 .. pi
+    ri, ro = span / 2.0 - 30.0, span / 2.0 - 30.0 + thick
+    z0, z1 = -depth / 2.0, depth / 2.0
+    quads = []
+    for (x0, y0), (x1, y1) in zip(half[:-1], half[1:]):
+        ia, ib = (ri * x0, ri * y0), (ri * x1, ri * y1)
+        oa, ob = (ro * x0, ro * y0), (ro * x1, ro * y1)
+        quads.append(_quad((*ia, z1), (*ib, z1), (*ib, z0), (*ia, z0)))                # intrados (faces the centre)
+        quads.append(_quad((*oa, z0), (*ob, z0), (*ob, z1), (*oa, z1)))                # extrados
+        quads.append(_quad((*ia, z1), (*oa, z1), (*ob, z1), (*ib, z1)))                # front face
+        quads.append(_quad((*ib, z0), (*ob, z0), (*oa, z0), (*ia, z0)))                # back face
+    tris = np.concatenate(quads)
+    return tris, _flat_normals(tris)
+
+
+def _y_turns():
+    """rotations about the y axis by general angles, built glam's way, that pass Model::new's assert (five inexact matrix entries)"""
+    out = []
+    for b in range(1, 40):
+        for d in range(1, 40):
+            if np.gcd(b, d) != 1 or b == d:
+                continue
+            m = affine_from_rotation_translation(quat_unit(0, b, 0, d), (0.0, 0.0, 0.0))
+            if is_rigid(m):
+                out.append(m)
+    return out
+
+
+def atrium(width=1920, height=1080, statue_level=2) -> SceneDesc:
+    """configs[3] (SURVEY 8d "atrium (columns/arches grid)"): a hall of 6 x 12 fluted columns (4 BLAS variants, turned about their axes by
+    quarter turns and by general glam-built rotations; three lie toppled under full 3-D rotations), two storeys of arches between them
+    (2 BLASes, ~230 instances, half of them quarter-turned), and 280 statues that are each their own BLAS — 293 models in all, so the
+    first-hit id `blas index as u8` (integrator.rs:184, main.rs:206) WRAPS for the statues nearest the camera — under skylight panels.
+    ~250 k instanced triangles over ~96 k unique ones, a world TLAS of ~590 leaves (tlas_bvh.rs:85-138: agglomerative, quadratic)."""
+    stone = [Lambertian.new((0.62, 0.58, 0.5)), Lambertian.new((0.55, 0.5, 0.45)), Lambertian.new((0.7, 0.66, 0.6)), Lambertian.new((0.5, 0.48, 0.46))]
+    X0, X1, Z0, Z1, Y0, Y1 = -1050.0, 1050.0, -3450.0, 450.0, 0.0, 1240.0
+    inward = (0.0, 500.0, -1500.0)
+    floor = _quad((X0, Y0, Z1), (X1, Y0, Z1), (X1, Y0, Z0), (X0, Y0, Z0))
+    ceil = _quad((X0, Y1, Z0), (X1, Y1, Z0), (X1, Y1, Z1), (X0, Y1, Z1))
+    back = _quad((X0, Y0, Z0), (X1, Y0, Z0), (X1, Y1, Z0), (X0, Y1, Z0))
+    right = _quad((X1, Y0, Z0), (X1, Y0, Z1), (X1, Y1, Z1), (X1, Y1, Z0))
+    left = _quad((X0, Y0, Z1), (X0, Y0, Z0), (X0, Y1, Z0), (X0, Y1, Z1))
+    models = []
+    # skylight panels: one emissive model each (a lights TLAS with several leaves and a light CDF with several entries)
+    for i, zc in enumerate((-300.0, -1200.0, -2100.0, -3000.0)):
+        q = _quad((-160.0, Y1 - 1.0, zc - 220.0), (160.0, Y1 - 1.0, zc - 220.0), (160.0, Y1 - 1.0, zc + 220.0), (-160.0, Y1 - 1.0, zc + 220.0))
+        e = 14.0 + 2.0 * i
+        models.append(_model(q, _flat_normals(q, inward), Emissive.new((e, e * 0.95, e * 0.85)), f"skylight{i}"))
+    shell = np.concatenate([floor, ceil, back])
+    models.append(_model(shell, _flat_normals(shell, inward), Lambertian.new((0.6, 0.6, 0.6)), "hall_shell"))
+    models.append(_model(right, _flat_normals(right, inward), Lambertian.new((0.6, 0.25, 0.2)), "hall_right"))
+    models.append(_model(left, _flat_normals(left, inward), Lambertian.new((0.25, 0.35, 0.55)), "hall_left"))
+    # columns: rows at x = -900, -600, -300 | aisle | 300, 600, 900; twelve bays along z
+    xs = [-900.0, -600.0, -300.0, 300.0, 600.0, 900.0]
+    zs = [300.0 - 300.0 * j for j in range(12)]
+    turns = _y_turns()
+    quarter = [np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0]], np.float32), np.array([[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0]], np.float32),
+               np.array([[0, 0, -1, 0], [0, 1, 0, 0], [1, 0, 0, 0]], np.float32)]
+    col_mats = [[] for _ in range(4)]
+    n = 0
+    for i, x in enumerate(xs):
+        for j, z in enumerate(zs):
+            v = (i + 2 * j) % 4
+            if n % 3 == 0:
+                m = IDENTITY_3x4.copy()
+            elif n % 3 == 1:
+                m = quarter[(n // 3) % 3].copy()
+            else:
+                m = turns[(7 * n) % len(turns)].copy()
+            m[:, 3] = (x, 0.0, z)
+            col_mats[v].append(m)
+            n += 1
+    # three toppled columns in the aisle: rotations about general axes (nine inexact entries), lying near the floor
+    col_mats[0].append(rigid_from_quat(2, -1, -2, 3, (-140.0, 60.0, -700.0)))
+    col_mats[1].append(rigid_from_quat(3, 2, -1, 3, (120.0, 70.0, -1650.0)))
+    col_mats[2].append(rigid_from_quat(4, -2, 2, 6, (-60.0, 80.0, -2500.0)))
+    for v in range(4):
+        t, nn = _column(v)
+        models.append(Model.new(t.astype(np.float32), nn.astype(np.float32), stone[v], np.stack(col_mats[v]), f"column{v}"))
+    # arches: along z inside every row, across x between neighbouring rows (not over the aisle), on two storeys
+    arch_mats = [[], []]
+    turn_y = np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0]], np.float32)      # the arch's span direction x -> z
+    for storey, y in enumerate((520.0, 860.0)):
+        for x in xs:
+            for j in range(len(zs) - 1):
+                m = turn_y.copy(); m[:, 3] = (x, y, (zs[j] + zs[j + 1]) / 2.0)
+                arch_mats[storey].append(m)
+        for i in (0, 1, 3, 4):
+            for z in zs:
+                m = IDENTITY_3x4.copy(); m[:, 3] = ((xs[i] + xs[i + 1]) / 2.0, y, z)
+                arch_mats[storey].append(m)
+    for storey in range(2):
+        t, nn = _arch(k=4 - storey, thick=34.0 + 10.0 * storey)
+        models.append(Model.new(t.astype(np.float32), nn.astype(np.float32), stone[2 + storey], np.stack(arch_mats[storey]), f"arch{storey}"))
+    # statues: each its own BLAS (a displaced icosphere with its own seed), the LAST ones placed nearest the camera along the aisle
+    palette = [Lambertian.new((0.75, 0.72, 0.68)), Lambertian.new((0.3, 0.5, 0.3)), Lambertian.new((0.55, 0.3, 0.25)), GGX.new_metal((0.9, 0.6, 0.2), 0.3),
+               Lambertian.new((0.25, 0.3, 0.55)), Specular.new((0.9, 0.9, 0.9)), Lambertian.new((0.7, 0.65, 0.3)), Dielectric.new((0.95, 0.95, 0.95), 1.5, None)]
+    spots = [(x, 564.0 + 44.0, z) for x in xs for z in zs]                                    # on the capitals: 72
+    spots += [(sx * 1000.0, 70.0, 375.0 - 150.0 * j) for j in range(26) for sx in (-1.0, 1.0)]  # along the side walls: 52
+    spots += [(sx * (150.0 + 75.0 * (j % 2)), 30.0, -3300.0 + 23.0 * j) for j in range(156) for sx in ((-1.0,) if j % 2 else (1.0,))]  # aisle, far -> near: 156
+    v0, f0 = _icosphere(statue_level)
+    for s, (x, y, z) in enumerate(spots):
+        disp = 1.0 + 0.35 * (_hash01(np.arange(len(v0)) + 7919 * (s + 1)) - 0.5)
+        radius = (42.0 + (s % 5) * 4.0) if s < 124 else (20.0 + (s % 5) * 2.0)             # the aisle's statues are small and stand clear of each other
+        p = v0 * disp[:, None] * radius + np.array([x, y, z])
+        tris = p[f0]
+        models.append(_model(tris, _flat_normals(tris), palette[s % len(palette)], f"statue{s}"))
+    cam = Camera.new((0.0, 180.0, 380.0), (0.0, 260.0, -1500.0), 60.0, width / height)
+    return SceneDesc.new(models, cam, "atrium")

@@ -371,6 +371,45 @@ def test_mesh_scenes_full_frame_bit_exact(api, oracle_mod, level):
     assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
 
 
+def test_atrium_full_frame_bit_exact(api, oracle_mod):
+    """BASELINE.json configs[3] as SURVEY 8(d) fixes it — the instanced atrium (scenes.atrium: 293 BLASes, ~590 TLAS leaves, quarter turns,
+    glam-built general rotations, ~250 k instanced triangles) — at the full 1920x1080, depth 8: accumulation, first-hit position, id
+    history, ray tallies.  The first-hit id is the BLAS arena index `as u8` (integrator.rs:184, main.rs:206): with more than 256 models it
+    WRAPS, and the statues nearest the camera are models 256..292."""
+    from path_tracer_amd import scenes
+    W, H = 1920, 1080
+    sc = scenes.atrium(W, H)
+    assert len(sc.models) > 256 and sum(len(m.matrices) for m in sc.models) > 500
+    r = api.Renderer(sc, W, H, max_bounces=8)
+    o = oracle_mod.Oracle(sc)
+    for which in (0, 1):
+        a, b = r.tlas_dump(which), o.tlas_dump(which)
+        for k in a:
+            assert_bit_equal(np.asarray(a[k]), np.asarray(b[k]), f"tlas{which}.{k}")
+    acc, pos, idb = r.render(0, 1)
+    st = r.stats()
+    assert st.stack_entries > 14 and not st.lds_scene
+    oacc, opos, oid, octr = o.render(W, H, 1, max_bounces=8)
+    assert_bit_equal(acc, oacc, "atrium 1080p accumulation"); assert_bit_equal(pos, opos, "position"); assert np.array_equal(idb, oid)
+    assert (st.rays_closest, st.rays_any, st.rays_light_closest) == (int(octr[0]), int(octr[1]), int(octr[2]))
+    # the wrap is really exercised: camera rays whose first hit is a model of index >= 256 (their id is index - 256)
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, W * H, 20000)
+    ro = np.zeros((len(px), 3), np.float32); rd = np.zeros((len(px), 3), np.float32)
+    for i, p in enumerate(px):
+        ro[i], rd[i] = o.primary_ray(W, H, int(p), 0)
+    h = r.trace_closest(ro, rd)
+    c = o.trace_closest(ro, rd)
+    for k in ("inst", "prim", "t", "u", "v"):
+        assert_bit_equal(h[k], c[k], f"atrium camera rays closest.{k}")
+    model_of_instance = np.concatenate([np.full(len(m.matrices), i) for i, m in enumerate(sc.models)])   # TLAS leaves in model order (tlas_bvh.rs:90-103)
+    hit = h["inst"] != 0xFFFFFFFF
+    first_model = model_of_instance[h["inst"][hit]]
+    assert (first_model >= 256).sum() > 50
+    wrapped = (idb.reshape(-1)[px[hit]] & 0xFFFF) == (first_model & 0xFF)
+    assert wrapped.all()
+
+
 def test_spilling_stacks_do_not_race_between_concurrent_launches(api, oracle_mod):
     """With only two stack levels in LDS every deeper level of every traversal lives in global memory; the shadow-ray launch and
     the BSDF-sampled NEE launch run side by side on two streams and must not share those slots (large lights so that the NEE

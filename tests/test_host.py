@@ -396,14 +396,16 @@ def test_bench_configurations_name_real_scenes():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     from path_tracer_amd import scenes
-    assert set(bench.CONFIGS) == {"cornell", "mesh82k", "mesh328k", "mixed", "spheres"}
+    assert set(bench.CONFIGS) == {"cornell", "mesh82k", "atrium", "mesh328k", "mixed", "spheres"}
     for name, cfg in bench.CONFIGS.items():
-        fn, kw, w, h, spp_own, spp_default, depth, what = cfg
+        fn, kw, w, h, spp_own, spp_default, depth, what, spp_cpu = cfg
         assert hasattr(scenes, fn), name
-        assert 1 <= spp_default <= spp_own and depth in (8, 16) and w * h >= 1920 * 1080
+        assert 1 <= spp_default <= spp_own and depth in (8, 16) and w * h >= 1920 * 1080 and 1 <= spp_cpu <= spp_default
     assert bench.make_scene(bench.CONFIGS["cornell"]).n_triangles() == 36
     assert bench.make_scene(bench.CONFIGS["mesh82k"]).n_triangles() == 81932
     assert bench.make_scene(bench.CONFIGS["mixed"]).n_triangles() == 36
+    atrium = bench.make_scene(bench.CONFIGS["atrium"])     # configs[3] as SURVEY 8(d) defines it
+    assert 240_000 <= atrium.n_triangles() <= 260_000 and len(atrium.models) > 256 and sum(len(m.matrices) for m in atrium.models) > 500
 
 
 def _world_triangles_f64(sc):
@@ -499,3 +501,12 @@ def test_general_rigid_instances(api, oracle_mod):
         t0, t1 = (boxes[:, :3] - o64) / d64, (boxes[:, 3:] - o64) / d64
     enter, leave = np.fmax(np.fmin(t0, t1).max(1), 5e-4), np.fmax(t0, t1).min(1)
     assert (enter > np.minimum(leave, bt[other] + 1.0)).mean() > 0.97, "the missed triangles lie outside the boxes the reference gives their instances"
+
+
+def test_write_accumulation_refuses_a_frame_of_another_size(api, cornell64):
+    """pt_write_accumulation copies width * height texels from each pointer: the wrappers (api.py, include/ptmi.hpp) check the sizes"""
+    r = api.Renderer(cornell64, 64, 64)
+    with pytest.raises(api.PtError):
+        r.write_accumulation(np.zeros((32, 32, 4), np.float32))
+    with pytest.raises(api.PtError):
+        r.write_accumulation(np.zeros((64, 64, 4), np.float32), np.zeros((64, 64, 4), np.float32), np.zeros((64, 32), np.uint32))

@@ -232,6 +232,8 @@ def main():
                        # cast more: camera rays outside the projection of the world's root box and BSDF-sampled NEE rays that miss the lights' root
                        # box are answered without a traversal.  Per step, rank 0:
                        "cast_Mray_per_s": rays / dt / 1e6,
+                       # whole job (all ranks), per step: exact integers, independent of the GPU count (the RNG is keyed by the global pixel)
+                       "job_per_step": {"casts": int(rays) // steps, "traversed": int(traversed) // steps, "paths": int(paths) // steps},
                        "rays_by_class": {"closest_traversed": traced_closest_local // steps,
                                          "closest_camera_rays_culled_by_projection": st.rays_primary_culled // steps,
                                          "any_traversed": st.rays_any // steps,

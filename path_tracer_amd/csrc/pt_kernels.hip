@@ -547,7 +547,7 @@ struct Blob
 {
     const uint4* nodes; // 2 words per node
     const uint4* tris;  // 3 words per triangle
-    const uint4* inst;  // 7 words per instance
+    const uint4* inst;  // INST_WORDS words per instance
     const uint2* leaves; // big-leaf table {first, count} (NODE_TRIS_BIG)
 };
 // triangles of a leaf link
@@ -566,11 +566,24 @@ struct LaneRay { f3 o, d, inv; };
 //   ((1*vx + 0*vy) + 0*vz) [+ -0]  ==  vx                      when vx != 0
 //                                  ==  zero signed by sign(vx) & sign(vy) & sign(vz)   when vx == +-0
 // (a sum of zeros is -0 only if every addend is -0); 1/v'x is then the world-space reciprocal or +-inf.
-__device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, const LaneRay& w, bool ray_finite, uint32_t& root)
+//
+// `root0` / `root1`: the instance record's copy of the BLAS root node (DInstance::root_node).  EAGER (BVH in global memory): the six
+// words a visit needs — matrix rows, meta, root node — are loaded TOGETHER, one memory round trip instead of three dependent ones
+// (meta -> rows; meta.root -> root node), and pinned so that the compiler cannot sink the row loads into the branch that uses them.
+__device__ __forceinline__ void pin(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+template <bool EAGER, bool ROOT_BOX>
+__device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, const LaneRay& w, bool ray_finite, uint4& root0, uint4& root1)
 {
-    const uint4* ip = bl.inst + 7u * inst;
-    const uint4 meta = ip[6];
-    root = meta.x;
+    const uint4* ip = bl.inst + INST_WORDS * inst;
+    uint4 r0, r1, r2;
+    if (EAGER)
+    {
+        r0 = ip[0]; r1 = ip[1]; r2 = ip[2];
+    }
+    const uint4 meta = ip[INST_META_WORD];
+    if (ROOT_BOX) { root0 = ip[INST_ROOT_WORD]; root1 = ip[INST_ROOT_WORD + 1u]; }
+    else root0.w = reinterpret_cast<const uint32_t*>(ip + INST_ROOT_WORD)[3];
+    if (EAGER) { pin(r0); pin(r1); pin(r2); }
     LaneRay r;
     if ((meta.w & INSTANCE_IDENTITY) != 0u && ray_finite)
     {
@@ -587,7 +600,7 @@ __device__ __forceinline__ LaneRay to_object(const Blob& bl, uint32_t inst, cons
         r.inv.z = w.d.z != 0.0f ? w.inv.z : asf(sd | 0x7f800000u);
         return r;
     }
-    const uint4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    if (!EAGER) { r0 = ip[0]; r1 = ip[1]; r2 = ip[2]; }
     r.o.x = ((asf(r0.x) * w.o.x + asf(r0.y) * w.o.y) + asf(r0.z) * w.o.z) + asf(r0.w);
     r.o.y = ((asf(r1.x) * w.o.x + asf(r1.y) * w.o.y) + asf(r1.z) * w.o.z) + asf(r1.w);
     r.o.z = ((asf(r2.x) * w.o.x + asf(r2.y) * w.o.y) + asf(r2.z) * w.o.z) + asf(r2.w);
@@ -614,7 +627,7 @@ __device__ __forceinline__ Blob stage_scene(const SceneView& sv, const uint4* __
     b.nodes = base;
     b.tris = base + 2u * sv.n_nodes;
     b.inst = base + 2u * sv.n_nodes + 3u * sv.n_tris;
-    b.leaves = reinterpret_cast<const uint2*>(base + 2u * sv.n_nodes + 3u * sv.n_tris + 7u * sv.n_instances);
+    b.leaves = reinterpret_cast<const uint2*>(base + 2u * sv.n_nodes + 3u * sv.n_tris + INST_WORDS * sv.n_instances);
     return b;
 }
 
@@ -831,7 +844,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                             if (bid == MISS_ID) ends = out->finalize_miss != 0u;
                             else
                             {
-                                const uint4 meta = bl.inst[7u * (bid >> prim_bits) + 6u];
+                                const uint4 meta = bl.inst[INST_WORDS * (bid >> prim_bits) + INST_META_WORD];
                                 emissive = ends = (meta.w & 0xffu) == (uint32_t)Q_TERMINAL;
                                 mat_id = meta.z;
                             }
@@ -863,7 +876,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                         // bin by shade class.  Surface classes get the whole hit record in queue order (the shading pass then reads
                         // linearly and never gathers by ray index); terminal entries stay {ray index, path id} + hits[ray index].
                         uint32_t cls = Q_COUNT;
-                        if (pending) cls = bid != MISS_ID ? (bl.inst[7u * (bid >> prim_bits) + 6u].w & 0xffu) : (uint32_t)Q_TERMINAL;
+                        if (pending) cls = bid != MISS_ID ? (bl.inst[INST_WORDS * (bid >> prim_bits) + INST_META_WORD].w & 0xffu) : (uint32_t)Q_TERMINAL;
                         const f4 hit{bt, hud / hdet, hvd / hdet, asf(bid)};
 #pragma unroll
                         for (uint32_t c = 0; c < Q_COUNT; ++c)
@@ -988,12 +1001,11 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 float t_enter = asf(e.y);
                 if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
                 {
-                    uint32_t blas_root;
-                    ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
+                    uint4 r0, r1;
+                    ob = to_object<!LDS_SCENE, true>(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, r0, r1);
                     in_blas = true;
                     blas_base = sp;
-                    const uint4 r0 = bl.nodes[2u * blas_root];
-                    if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                    if (!slab(r0, r1, ob.o, ob.inv, t_max, t_enter)) continue;
                     link = r0.w;
                 }
                 const uint32_t kkind = link >> NODE_KIND_SHIFT, kpay = link & NODE_PAYLOAD_MASK;
@@ -1059,13 +1071,13 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             {
                 // TLAS leaf: transform the ray, run the BLAS with the current t_max  tlas.rs:88-99.  BLAS::intersect pushes its root
                 // with t_enter = 0 and no box test (blas.rs:217) and pops it at once: that pop happens here, in the same step.
-                uint32_t blas_root;
+                uint4 root0, root1;
                 inst = link & NODE_PAYLOAD_MASK;
-                ob = to_object(bl, inst, w, ray_finite, blas_root);
+                ob = to_object<!LDS_SCENE, false>(bl, inst, w, ray_finite, root0, root1);
                 in_blas = true;
                 blas_base = sp;
                 if (0.0f > t_max) continue;                  // the root's pop test  blas.rs:222-225
-                link = reinterpret_cast<const uint32_t*>(bl.nodes + 2u * blas_root)[3];
+                link = root0.w;
                 t_est = 0.0f;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
@@ -1332,12 +1344,11 @@ __device__ __forceinline__ void any_body(const SceneView& sv, const Blob& bl, co
             if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
             {
                 // TLAS leaf: transform the ray; the BLAS root's box is the first thing BLAS::any_intersect tests  blas.rs:262-264
-                uint32_t blas_root;
-                ob = to_object(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, blas_root);
+                uint4 r0, r1;
+                ob = to_object<!LDS_SCENE, true>(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, r0, r1);
                 in_blas = true;
                 blas_base = sp;
-                const uint4 r0 = bl.nodes[2u * blas_root];
-                if (!slab(r0, bl.nodes[2u * blas_root + 1u], ob.o, ob.inv, t_max, t_enter)) continue;
+                if (!slab(r0, r1, ob.o, ob.inv, t_max, t_enter)) continue;
                 link = r0.w;
             }
             uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;

@@ -766,6 +766,7 @@ int HostScene::flatten(std::string* err)
                 std::memcpy(dst[k], rows, sizeof(rows));
             }
             d.root = blas_root_at[hi.model];
+            d.root_node = f.nodes[d.root];
             d.blas = hi.blas;
             d.material = (uint32_t)blas[hi.model].material;
             switch (materials[d.material].kind)

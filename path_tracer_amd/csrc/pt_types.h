@@ -7,7 +7,7 @@
 //   tri_isect  : 48 B  Havel-Herout planes n0|d0, n1|d1, n2|d2 (primitive.rs:20-26), BLAS-leaf order
 //   tri_shade  : 48 B  vertex normals  (3 x float4, w unused)
 //   tri_pos    : 48 B  vertex positions (3 x float4, w unused)  - only light sampling reads it
-//   instances  : 112 B inverse 3x4 | forward 3x4 | blas root, blas id, material, first_id
+//   instances  : 144 B inverse 3x4 | blas root, blas id, material, class | copy of the BLAS root node | forward 3x4
 //   materials  : 48 B
 //   lights     : 16 B  { triangle, material, pdf, cdf }
 // Traversal touches nodes + tri_isect + instances only ("scene blob"); when that fits it is staged in LDS.
@@ -47,16 +47,23 @@ struct alignas(16) DTriIsect { f4 n0, n1, n2; };
 static_assert(sizeof(DTriIsect) == 48, "");
 struct alignas(16) DTriVerts { f4 a, b, c; };
 
+// One TLAS leaf.  What a traversal needs when it enters the instance is the FIRST 96 bytes, one contiguous run of six 16-byte words that
+// are loaded together: the inverse matrix, the meta word and a COPY of the BLAS root node (its link is what BLAS::intersect starts from,
+// blas.rs:216-217; its box is what BLAS::any_intersect tests first, blas.rs:262-264).  Without the copy an instance visit is three
+// dependent memory round trips (meta -> matrix rows, meta.root -> root node); on BVHs in global memory 88 % of the atrium's wave-steps
+// execute the instance section for ~10 of 64 lanes (profiles/r04_step_stats_atrium.md) and every lane of the wave waits for them.
 struct alignas(16) DInstance
 {
     float inv[12];  // rows of the inverse instance matrix (ray -> object space)       tlas_bvh.rs:41-43
-    float fwd[12];  // rows of the instance matrix (object normal -> world)            tlas.rs:105
     uint32_t root;  // absolute node index of the BLAS root
     uint32_t blas;  // BLAS (= model) index in its TLAS arena; world: first_id source   integrator.rs:184
     uint32_t material;
     uint32_t qclass; // bits 7:0 shade-queue class of the material (Q_*), bit 8 INSTANCE_IDENTITY
+    DNode root_node; // nodes[root]
+    float fwd[12];  // rows of the instance matrix (object normal -> world)            tlas.rs:105
 };
-static_assert(sizeof(DInstance) == 112, "");
+static_assert(sizeof(DInstance) == 144, "");
+enum : uint32_t { INST_WORDS = 9u, INST_META_WORD = 3u, INST_ROOT_WORD = 4u }; // 16-byte words per record; where meta and the root node copy start
 
 enum : uint32_t { MAT_LAMBERTIAN = 0, MAT_EMISSIVE = 1, MAT_SPECULAR = 2, MAT_GGX_METAL = 3, MAT_GGX_DIELECTRIC = 4, MAT_DIELECTRIC = 5 };
 

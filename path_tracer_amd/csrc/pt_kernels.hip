@@ -41,9 +41,14 @@ namespace {
 #define PT_REFILL_BELOW_ANY PT_REFILL_BELOW
 #endif
 // waves per SIMD the compiler must leave room for in the traversal kernels (second parameter of __launch_bounds__).  BVH in LDS: 4 for
-// both (3 / 5 / 2: within noise).  BVH in global memory (the kernels wait on L2): the any-hit kernel fits 96 VGPRs and runs 5 waves; the
-// closest-hit kernel is asked for 3 — it still allocates ~120 VGPRs, but is scheduled more loosely — same-box A/B on the 82 k / 328 k
-// meshes against 4 / 4: -3.8 % / -5 % (3 / 3: -2 / -4.5 %, 5 / 5: -1.5 / -2 %, 2 / 2: -2 / -3.5 %).
+// both (3 / 5 / 2: within noise).  BVH in global memory: 5 for both.  The kernels wait on L2 — one more DEPENDENT load per branch level,
+// an L1 hit, costs the closest-hit kernel 10-13 % (-DPT_PROBE_LATENCY=1, round 4) — so a fifth wave pays, provided it is not bought
+// with scratch: round 2 asked the compiler for 5 or 6 waves of the kernel as it was (123-127 VGPRs wanted: 72-164 B of scratch) and got
+// +-0 / -15 %; round 4 first took the register peak away — the closest-hit leaves of these kernels test ONE triangle at a time instead of
+// two side by side (PT_PAIR_LEAVES_GLOBAL = 0: 123 -> 105 VGPRs) — and then 96 VGPRs cost 8-12 B of scratch.  Same-box A/B, whole frame
+// at 64 spp, atrium / 82 k mesh / 328 k mesh / spheres: pairs at 4 waves 325 / 73.6 / 123.5 / 54.4 ms, single at 4 waves 309 / 70.1 /
+// 119.6 / 52.9, single at 5 waves 281 / 67.2 / 115.0 / 49.6 (-14 / -9 / -7 / -9 %); 6 waves (80 VGPRs, 64-88 B of scratch, 13 stack
+// levels in LDS) 315 / 71.7 / 124.0 / 54.4; any-hit alone at 6: 295 / 68.3 / 114.7 / 51.4.
 #ifndef PT_WAVES_LDS_BVH
 #define PT_WAVES_LDS_BVH 4
 #endif
@@ -51,7 +56,7 @@ namespace {
 #define PT_WAVES_LDS_BVH_ANY 4
 #endif
 #ifndef PT_WAVES_GLOBAL_BVH
-#define PT_WAVES_GLOBAL_BVH 3
+#define PT_WAVES_GLOBAL_BVH 5
 #endif
 #ifndef PT_WAVES_GLOBAL_BVH_ANY
 #define PT_WAVES_GLOBAL_BVH_ANY 5
@@ -70,6 +75,14 @@ namespace {
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
+#endif
+// closest-hit leaves of BVHs in global memory: two triangles side by side (as the LDS scenes do: -2.2 ms per Cornell frame) or one at a
+// time (18 VGPRs fewer, which is what lets these kernels run five waves per SIMD: see PT_WAVES_GLOBAL_BVH)
+#ifndef PT_PAIR_LEAVES_GLOBAL
+#define PT_PAIR_LEAVES_GLOBAL 0
+#endif
+#ifndef PT_PROBE_LATENCY
+#define PT_PROBE_LATENCY 0 // 1: one more dependent (L1-hit) load per branch level of k_closest: how much does the kernel care about memory latency?
 #endif
 // PT_WAVE_TIMES (variant builds, tools/wave_times.py): when the waves of a k_closest launch start, first have rays, find the queue empty, end
 #ifndef PT_WAVE_TIMES
@@ -941,7 +954,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                 }
                 else
                 {
-                    const f4 a = ra[mine];
+                    const f4 a = ra[mine]; // (asking for both words of the ray together: +-0, and 8 B more scratch at five waves)
                     w.o = xyz(a);
                     t_max = a.w;
                 }
@@ -1092,7 +1105,16 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS && kind == NODE_BRANCH; ++lvl)
             {
                 const uint4* cp = bl.nodes + 2u * payload; // the children are one contiguous 64-byte record pair
+#if PT_PROBE_LATENCY
+                // sensitivity probe (not a product build): the right child's words are loaded only after the left child's have arrived
+                // (same 64-byte record: an L1 hit) — one more DEPENDENT memory round trip per branch level, no other change
+                const uint4 l0 = cp[0], l1 = cp[1];
+                uint32_t zero = l0.w;
+                asm volatile("v_and_b32 %0, 0, %0" : "+v"(zero));
+                const uint4 r0 = cp[2u + zero], r1 = cp[3u + zero];
+#else
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
+#endif
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);
@@ -1141,6 +1163,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                     }
                 };
                 uint32_t k = 0;
+                if (LDS_SCENE || PT_PAIR_LEAVES_GLOBAL)
                 for (; k + 1u < count; k += 2u)
                 {
                     const uint4* tp = bl.tris + 3u * (first + k);
@@ -1148,7 +1171,8 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                     accept(ea, first + k);
                     accept(eb, first + k + 1u);
                 }
-                if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
+                if (LDS_SCENE || PT_PAIR_LEAVES_GLOBAL) { if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k); }
+                else for (; k < count; ++k) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
                 if (bt != bt) { sp = stk.empty(); in_blas = false; } // NaN t_max: nothing else can be accepted anywhere
             }
         }

@@ -270,6 +270,9 @@ int pt_multi_get_stats(pt_multi* m, pt_stats* sum);   /* counters summed over th
  * [4] NEE-chain slots, [6] NEE-chain rays traced, [7] of those hitting a light, [8..12] shade-queue slots (terminal, lambert,
  * specular, dielectric, ggx), [13] closest rays traced, [14] shadow rays traced.  Slots include the holes producers return. */
 int pt_last_batch_counters(pt_ctx* ctx, uint32_t* rows16, uint32_t cap_rows, uint32_t* n_rows);
+/* diagnostic (tools/shade_access_bench.py): path ids of slots [first, first + count) of a surface class's shade queue as the LAST batch's
+ * last bounce left it (the order its shading pass read them in); 0xffffffff marks a slot no ray took.  qclass: 1 lambert .. 4 ggx */
+int pt_last_batch_shade_pids(pt_ctx* ctx, uint32_t qclass, uint32_t first, uint32_t count, uint32_t* pids);
 /* diagnostic, meaningful only with a -DPT_STEP_STATS=1 build of the kernels (tools/step_stats.py): per bounce, 8 words: traversal
  * wave-steps of the world closest-hit kernel, lanes active in them, lanes taking the instance / branch / triangle-leaf section, wave-steps
  * in which some lane took the instance / branch / leaf section */

@@ -32,7 +32,7 @@ EXPORTS = [
     "pt_camera_matrices", "pt_set_environment", "pt_create_ray", "pt_render", "pt_render_device", "pt_reset_accumulation", "pt_accum_device_ptr",
     "pt_read_accumulation", "pt_read_frame", "pt_write_accumulation", "pt_render_samples", "pt_active_pixels", "pt_local_rows", "pt_set_stream", "pt_synchronize", "pt_camera_input", "pt_camera_angles", "pt_frame", "pt_inv_projection", "pt_present", "pt_post_velocity", "pt_post_reproject", "pt_post_tonemap", "pt_post_rgb8", "pt_present_rgb8", "pt_write_image", "pt_trace_closest", "pt_trace_any",
     "pt_ss_sobol", "pt_math_batch", "pt_material_eval", "pt_blas_count", "pt_blas_dump", "pt_tlas_dump", "pt_tlas_instances", "pt_light_cdf",
-    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_step_stats",
+    "pt_triangle_dump", "pt_get_stats", "pt_reset_stats", "pt_last_batch_counters", "pt_last_batch_shade_pids", "pt_last_batch_step_stats",
     "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_ctx", "pt_multi_render", "pt_multi_framebuffer_device_ptr",
     "pt_multi_reset_accumulation", "pt_multi_get_stats", "pt_multi_used_rccl", "pt_multi_write_image",
 ]
@@ -161,6 +161,7 @@ def lib():
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
         L.pt_last_batch_counters.argtypes = [vp, vp, u32, C.POINTER(u32)]
+        L.pt_last_batch_shade_pids.argtypes = [vp, u32, u32, u32, vp]
         _lib = L
     return _lib
 
@@ -520,6 +521,11 @@ class Renderer:
         n = C.c_uint32()
         self._chk(self.L.pt_last_batch_counters(self.ctx, _p(rows), rows.shape[0], C.byref(n)))
         return rows[: n.value]
+
+    def last_batch_shade_pids(self, qclass, first, count):
+        out = np.zeros(count, np.uint32)
+        self._chk(self.L.pt_last_batch_shade_pids(self.ctx, qclass, first, count, _p(out)))
+        return out
 
     def last_batch_step_stats(self):
         rows = np.zeros((self.cfg.max_bounces + 2, 8), np.uint32)

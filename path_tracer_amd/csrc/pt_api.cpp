@@ -2103,6 +2103,20 @@ int pt_last_batch_counters(pt_ctx* c, uint32_t* rows16, uint32_t cap_rows, uint3
     return PT_OK;
 }
 
+// diagnostic (tools/shade_access_bench.py): the path ids of the LAST batch's last bounce in the order its shading pass read them — word 3 of
+// array `a` of the class's shade queue, which nothing overwrites after the batch's last traversal launch.  HOLE (0xffffffff) = a slot no ray took.
+int pt_last_batch_shade_pids(pt_ctx* c, uint32_t qclass, uint32_t first, uint32_t count, uint32_t* pids)
+{
+    if (!c || !pids || qclass == Q_TERMINAL || qclass >= Q_COUNT) return PT_ERR_ARG;
+    const pt_ctx::Pipe& pp = c->pipe[c->last_pipe];
+    if (!pp.wb.q_shade_base || !((pp.wb.class_mask >> qclass) & 1u)) return PT_ERR_STATE;
+    if ((uint64_t)first + count > pp.wb.q_stride) return PT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const ShadeQueue q = shade_queue(pp.wb, qclass);
+    HIPCHK(c, hipMemcpy2D(pids, 4, reinterpret_cast<const uint8_t*>(q.a + first) + 12, 16, 4, count, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 // diagnostic (PT_STEP_STATS variant builds, tools/step_stats.py): words 8..15 of the closest-hit cursor lines of the last batch, summed
 // over the 64 lines, one row of 8 words per bounce
 int pt_last_batch_step_stats(pt_ctx* c, uint32_t* rows8, uint32_t cap_rows, uint32_t* n_rows)

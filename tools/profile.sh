@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/<tag>_*: one kernel-trace pass of a bench.py step and separate --pmc passes (never combined with other
 # trace domains; FETCH_SIZE and WRITE_SIZE each need a pass of their own on gfx950).  Run on the GPU box:
-#   bash tools/profile.sh <tag> [bench.py arguments, e.g. --config mesh82k --spp 8]      (default tag r03_cornell, --spp 43 for the PMC passes)
+#   bash tools/profile.sh <tag> [bench.py arguments, e.g. --config mesh82k --spp 8]      (default tag r04_cornell, --spp 43 for the PMC passes)
 # (every pass with --pipelines 1: batches one after another, so that kernel durations and counters are not those of two overlapping pipelines)
 # then  python tools/profile_summary.py gpurun_out/prof_<tag> <tag>
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03_cornell}; shift || true
+TAG=${1:-r04_cornell}; shift || true
 ARGS="$@"
 case "$ARGS" in *--spp*) PMC_ARGS="$ARGS";; *) PMC_ARGS="$ARGS --spp 43";; esac
 O=$R/gpurun_out/prof_$TAG

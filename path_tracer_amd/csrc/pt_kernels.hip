@@ -81,9 +81,6 @@ namespace {
 #ifndef PT_PAIR_LEAVES_GLOBAL
 #define PT_PAIR_LEAVES_GLOBAL 0
 #endif
-#ifndef PT_PROBE_LATENCY
-#define PT_PROBE_LATENCY 0 // 1: one more dependent (L1-hit) load per branch level of k_closest: how much does the kernel care about memory latency?
-#endif
 // PT_WAVE_TIMES (variant builds, tools/wave_times.py): when the waves of a k_closest launch start, first have rays, find the queue empty, end
 #ifndef PT_WAVE_TIMES
 #define PT_WAVE_TIMES 0
@@ -1105,16 +1102,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             for (int lvl = 0; lvl < PT_BRANCH_LEVELS && kind == NODE_BRANCH; ++lvl)
             {
                 const uint4* cp = bl.nodes + 2u * payload; // the children are one contiguous 64-byte record pair
-#if PT_PROBE_LATENCY
-                // sensitivity probe (not a product build): the right child's words are loaded only after the left child's have arrived
-                // (same 64-byte record: an L1 hit) — one more DEPENDENT memory round trip per branch level, no other change
-                const uint4 l0 = cp[0], l1 = cp[1];
-                uint32_t zero = l0.w;
-                asm volatile("v_and_b32 %0, 0, %0" : "+v"(zero));
-                const uint4 r0 = cp[2u + zero], r1 = cp[3u + zero];
-#else
                 const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
-#endif
                 const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
                 float tl, tr;
                 const bool hl = slab(l0, l1, o, inv, t_max, tl);

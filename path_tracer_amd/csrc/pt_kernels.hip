@@ -42,7 +42,7 @@ namespace {
 #endif
 // waves per SIMD the compiler must leave room for in the traversal kernels (second parameter of __launch_bounds__).  BVH in LDS: 4 for
 // both (3 / 5 / 2: within noise).  BVH in global memory: 5 for both.  The kernels wait on L2 — one more DEPENDENT load per branch level,
-// an L1 hit, costs the closest-hit kernel 10-13 % (-DPT_PROBE_LATENCY=1, round 4) — so a fifth wave pays, provided it is not bought
+// an L1 hit, costs the closest-hit kernel 10-13 % (experiments/r04_latency_probe.patch, round 4) — so a fifth wave pays, provided it is not bought
 // with scratch: round 2 asked the compiler for 5 or 6 waves of the kernel as it was (123-127 VGPRs wanted: 72-164 B of scratch) and got
 // +-0 / -15 %; round 4 first took the register peak away — the closest-hit leaves of these kernels test ONE triangle at a time instead of
 // two side by side (PT_PAIR_LEAVES_GLOBAL = 0: 123 -> 105 VGPRs) — and then 96 VGPRs cost 8-12 B of scratch.  Same-box A/B, whole frame

@@ -782,3 +782,17 @@ def test_general_rigid_instances_bit_exact(api, oracle_mod):
                 assert_bit_equal(a[k], b[k], f"random rays tlas{which} closest.{k}")
         tm = rng.uniform(0, 800, n).astype(np.float32)
         assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))
+
+
+def test_atrium_with_every_stack_level_spilled(api, oracle_mod):
+    """The atrium's traversal stack is deeper than the 14 levels kept in LDS (TLAS depth 15 + BLAS depth): with only TWO levels in LDS nearly every
+    push and pop of both traversal kernels goes through the global spill area, TLAS entries lying under a BLAS's among them; per-sample radiance
+    of a small frame (all four surface classes are present: the statues)."""
+    from path_tracer_amd import scenes
+    W, H = 240, 136
+    sc = scenes.atrium(W, H)
+    r = api.Renderer(sc, W, H, max_bounces=8, stack_lds_levels=2)
+    g = r.render_samples(0, 3)
+    assert r.stats().stack_entries > 14
+    c = oracle_mod.Oracle(sc).render_samples(W, H, 3, max_bounces=8)
+    assert_bit_equal(g, c, "atrium, spill-everything traversal")

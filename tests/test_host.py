@@ -510,3 +510,37 @@ def test_write_accumulation_refuses_a_frame_of_another_size(api, cornell64):
         r.write_accumulation(np.zeros((32, 32, 4), np.float32))
     with pytest.raises(api.PtError):
         r.write_accumulation(np.zeros((64, 64, 4), np.float32), np.zeros((64, 64, 4), np.float32), np.zeros((64, 32), np.uint32))
+
+
+def test_rigid_assert_agrees_between_python_library_and_oracle(api, oracle_mod):
+    """Model::new's `scale == ONE` assert (model.rs:40-44) in three implementations — scene_desc.is_rigid (numpy binary32), libptmi's pt_add_model
+    (PT_ERR_NONRIGID) and the oracle's — on glam-built matrices of random unit quaternions, about a third of which pass: the scenes' instance matrices
+    are filtered by the first and must be accepted by the other two, and a matrix the reference would refuse must be refused by all."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import SceneDesc, affine_from_rotation_translation, is_rigid, quat_unit
+    rng = np.random.default_rng(17)
+    base = scenes.cornell_box(32, 32)
+    seen = {True: 0, False: 0}
+    for _ in range(120):
+        q = rng.integers(-60, 61, 4)
+        if not q.any():
+            continue
+        m = affine_from_rotation_translation(quat_unit(*q), rng.integers(-50, 51, 3).astype(np.float32))
+        want = is_rigid(m)
+        seen[want] += 1
+        sc = SceneDesc.new(list(base.models), base.camera)
+        sc.models[4] = type(sc.models[4])(sc.models[4].positions, sc.models[4].normals, sc.models[4].material, m[None].copy(), "probe")
+        try:
+            r = api.Renderer(sc, 32, 32)
+            got_lib = True
+            r.close()
+        except api.PtError as e:
+            assert e.code == -4
+            got_lib = False
+        try:
+            oracle_mod.Oracle(sc)
+            got_or = True
+        except ValueError:
+            got_or = False
+        assert got_lib == want and got_or == want, (q, want, got_lib, got_or)
+    assert seen[True] >= 20 and seen[False] >= 20

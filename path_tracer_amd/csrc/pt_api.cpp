@@ -889,7 +889,13 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
             size_t held = 0;
             for (const pt_ctx::Pipe& pp : c->pipe)
                 for (const DevBuf& b : pp.pool) held += b.bytes;
-            max_paths = (size_t)((double)(free_b + held) * 0.75 / 410.0);
+            // bytes of wavefront state per path (ensure_wavefront): 323 in records, ray queues and terminal queues + 54 per surface class present
+            // in the scene (its 48-byte shade queue with an eighth of slack) + 4 with volumes.  (Rounds 1-3 assumed 410 whatever the scene:
+            // right for one class, but the four-class atrium then asked for 268 GiB of a 268.2 GiB device.)
+            uint32_t n_classes = 0;
+            for (uint32_t q = 1; q < Q_COUNT; ++q) n_classes += c->class_present[q] ? 1u : 0u;
+            const double per_path = 330.0 + 56.0 * std::max(n_classes, 1u) + (c->sv.has_volumes ? 4.0 : 0.0) + 24.0;
+            max_paths = (size_t)((double)(free_b + held) * 0.85 / per_path);
         }
         max_paths = std::min<size_t>(std::max<size_t>(max_paths, 1u << 20), (1ull << 29) - 1);
     }

@@ -796,3 +796,56 @@ def test_atrium_with_every_stack_level_spilled(api, oracle_mod):
     assert r.stats().stack_entries > 14
     c = oracle_mod.Oracle(sc).render_samples(W, H, 3, max_bounces=8)
     assert_bit_equal(g, c, "atrium, spill-everything traversal")
+
+
+@pytest.mark.parametrize("scale", [1e-18, 1e-3, 1.0, 1e9, 1e12, 1e13, 1e17])
+def test_degenerate_triangles_and_extreme_scales(api, oracle_mod, scale):
+    """Triangles the OBJ files of the world contain and the reference neither filters nor guards against: zero-area ones (two equal vertices, three
+    collinear ones: n0 = 0, so the Havel-Herout planes n1, n2 are 0 / 0 = NaN, primitive.rs:31-54), slivers, and — through the scale — coordinates whose
+    products leave the binary32 range at either end (denormal plane terms at 1e-18, 1e34-sized dot products at 1e17: infinities and 0 * inf in the
+    slab tests).  Whatever the reference's arithmetic makes of them, both sides must make the same of them: hit records and any-hit answers as bit patterns."""
+    from path_tracer_amd import scenes
+    from path_tracer_amd.scene_desc import Emissive, Lambertian, Model, SceneDesc
+    rng = np.random.default_rng(23)
+    n = 400
+    c = rng.uniform(-100, 100, (n, 1, 3))
+    p = c + rng.normal(0, 12.0, (n, 3, 3))
+    p[0:40, 1] = p[0:40, 0]                                                       # two equal vertices
+    p[40:80, 2] = p[40:80, 0] + 2.5 * (p[40:80, 1] - p[40:80, 0])                 # collinear
+    p[80:120, 2] = p[80:120, 0] + (p[80:120, 1] - p[80:120, 0]) * 0.5 + rng.normal(0, 1e-4, (40, 3))   # slivers
+    p[120:130] = p[120:121]                                                       # ten coincident copies of one triangle
+    nr = rng.normal(size=(n, 3, 3)); nr /= np.linalg.norm(nr, axis=2, keepdims=True)
+    s = np.float32(scale)
+    pos = (p.astype(np.float32) * s).astype(np.float32)
+    assert np.isfinite(pos).all()
+    light = (np.array([[[-30, 150, -30], [30, 150, -30], [30, 150, 30]]], np.float32) * s).astype(np.float32)
+    ln = np.tile(np.array([0, -1, 0], np.float32), (1, 3, 1))
+    sc = SceneDesc.new([Model.new(pos, nr.astype(np.float32), Lambertian.new((0.6, 0.6, 0.6)), None, "soup"),
+                        Model.new(light, ln, Emissive.new((5, 5, 5)), None, "light")], scenes.reference_camera(1.0))
+    r = api.Renderer(sc, 32, 32)
+    o = oracle_mod.Oracle(sc)
+    a, b = r.blas_dump(0), o.blas_dump(0)
+    for k in a:
+        assert_bit_equal(np.asarray(a[k]), np.asarray(b[k]), f"blas.{k} at scale {scale}")
+    m = 8000
+    O = (rng.uniform(-160, 160, (m, 3)) * scale).astype(np.float32)
+    D = rng.normal(size=(m, 3)); D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    tgt = (p[rng.integers(0, n, m // 2)].mean(1) * scale)                         # half of the rays aimed at triangle centroids (degenerate ones included)
+    d2 = tgt - O[: m // 2].astype(np.float64)
+    D[: m // 2] = (d2 / np.maximum(np.linalg.norm(d2, axis=1, keepdims=True), 1e-300)).astype(np.float32)
+    D[~np.isfinite(D).all(1)] = np.array([0, 0, 1], np.float32)
+    g, c2 = r.trace_closest(O, D), o.trace_closest(O, D)
+    for k in ("inst", "prim", "t", "u", "v"):
+        assert_bit_equal(g[k], c2[k], f"closest.{k} at scale {scale}")
+    # (hits exist from 1e-3 to 1e13; their number changes at 1e9 and again at 1e12, where |n0|^2 overflows and the planes n1, n2 collapse to 0:
+    # below 1e-3 everything lies nearer than EPSILON, at 1e17 every dot product is infinite)
+    if 1e-3 <= scale <= 1e13:
+        assert np.isfinite(c2["t"]).sum() > m // 16
+    tm = (rng.uniform(0, 400, m) * scale).astype(np.float32)
+    assert np.array_equal(r.trace_any(O, D, tm), o.trace_any(O, D, tm))
+    if scale == 1.0:
+        # and a whole (tiny) frame through the integrator with these triangles in the scene: NaN planes reach the shading normals
+        sc2 = SceneDesc.new(scenes.cornell_models()[:4] + [Model.new(pos * np.float32(0.8), nr.astype(np.float32), Lambertian.new((0.6, 0.6, 0.6)), None, "soup")],
+                            scenes.reference_camera(1.5))
+        want = oracle_mod.Oracle(sc2).render_samples(48, 32, 3, max_bounces=6)
+        assert_bit_equal(api.Renderer(sc2, 48, 32, max_bounces=6).render_samples(0, 3), want, "frame with degenerate triangles")

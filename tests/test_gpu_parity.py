@@ -834,6 +834,11 @@ def test_degenerate_triangles_and_extreme_scales(api, oracle_mod, scale):
     d2 = tgt - O[: m // 2].astype(np.float64)
     D[: m // 2] = (d2 / np.maximum(np.linalg.norm(d2, axis=1, keepdims=True), 1e-300)).astype(np.float32)
     D[~np.isfinite(D).all(1)] = np.array([0, 0, 1], np.float32)
+    # rays that are not numbers: infinite / NaN origin components, zero and NaN direction components (Ray::new divides by them, ray.rs:16)
+    special = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0], np.float32)
+    for i in range(m - 60, m):
+        if i % 2: O[i, rng.integers(0, 3)] = special[rng.integers(0, 3)]
+        else: D[i, rng.integers(0, 3)] = special[rng.integers(2, 5)]
     g, c2 = r.trace_closest(O, D), o.trace_closest(O, D)
     for k in ("inst", "prim", "t", "u", "v"):
         assert_bit_equal(g[k], c2[k], f"closest.{k} at scale {scale}")

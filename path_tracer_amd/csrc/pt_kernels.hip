@@ -140,6 +140,12 @@ template <bool LDS_SCENE> struct Refill
     static constexpr int kBelowAny = LDS_SCENE ? PT_REFILL_BELOW_ANY : PT_REFILL_BELOW_GLOBAL_BVH;
 };
 
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f)
+{
+    const uint32_t q = __umulhi(f.magic, n);
+    const uint32_t t = ((n - q) >> 1) + q;
+    return f.one ? n : (t >> f.shift);
+}
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 {
@@ -665,7 +671,10 @@ struct ClosestOut
     f4* radiance;
     f4* first_pos;
     uint32_t* first_id;
-    uint32_t keep_id_from, keep_pos_from; // path ids at or above these still need first_id / first_pos (last samples of the batch)
+    // environment-map builds of the frame only (a primary miss is then shaded by the terminal pass, but its id / position defaults are written here):
+    // how a path id splits into (sample, pixel) — RenderParams::blk_* — and from which batch-local sample on id / position are kept
+    uint32_t keep_s_id, keep_s_pos, blk_log, n_blk, blk_last, act_pixels;
+    FastDiv div_blk_paths, div_blk_last;
     uint32_t finalize_miss;               // 0 when an environment map is set: misses then go to the terminal queue like any bounce
     // CLOSEST_WORLD: paths that end at this hit or miss are finished here
     const DPathRec* rec;
@@ -819,23 +828,21 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                         // one byte per camera ray instead of a 16-byte radiance record for the (usually many) rays that leave at once:
                         // k_accumulate reads PRIMARY_MISS as radiance (0.006, 0.006, 0.006)
                         if (pending) out->occl[ray_idx] = missed ? (uint8_t)PRIMARY_MISS : (uint8_t)0u;
-                        if (missed)
-                        {
-                            if (ray_idx >= out->keep_id_from) out->first_id[ray_idx - out->keep_id_from] = 255u;
-                            if (ray_idx >= out->keep_pos_from)
-                            {
-                                const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out->first_pos[ray_idx - out->keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
-                            }
-                        }
-                        else if (pending && bid == MISS_ID)
+                        // (a plain miss leaves nothing else behind: k_accumulate reads PRIMARY_MISS as id 255, position r.at(1e5), integrator.rs:156-157)
+                        if (!missed && pending && bid == MISS_ID)
                         {
                             // environment map present: the terminal pass shades the miss; defaults of integrator.rs:156-157 still apply
-                            if (ray_idx >= out->keep_id_from) out->first_id[ray_idx - out->keep_id_from] = 255u;
-                            if (ray_idx >= out->keep_pos_from)
+                            const FastDiv dbp{out->div_blk_paths.magic, out->div_blk_paths.shift, out->div_blk_paths.one, out->div_blk_paths.d};
+                            const FastDiv dbl{out->div_blk_last.magic, out->div_blk_last.shift, out->div_blk_last.one, out->div_blk_last.d};
+                            const uint32_t b = fastdiv(ray_idx, dbp), rem = ray_idx - b * (out->act_pixels << out->blk_log);
+                            const bool short_blk = b + 1u == out->n_blk;
+                            const uint32_t k = short_blk ? fastdiv(rem, dbl) : (rem >> out->blk_log);
+                            const uint32_t sl = (b << out->blk_log) + (rem - k * (short_blk ? out->blk_last : (1u << out->blk_log)));
+                            if (sl >= out->keep_s_id) out->first_id[(sl - out->keep_s_id) * out->act_pixels + k] = 255u;
+                            if (sl == out->keep_s_pos)
                             {
                                 const f3 far = fma3(w.d, bc3(1e5f), w.o);
-                                out->first_pos[ray_idx - out->keep_pos_from] = f4{far.x, far.y, far.z, 1e5f};
+                                out->first_pos[k] = f4{far.x, far.y, far.z, 1e5f};
                             }
                         }
                         qm = __ballot(pending && !missed);
@@ -1498,24 +1505,34 @@ __global__ void __launch_bounds__(256, BVH != 0 ? PT_WAVES_LDS_BVH : PT_WAVES_GL
 // ------------------------------------------------------------------------------------------------ path bookkeeping
 struct PixelId { uint32_t gpixel, sample, lpixel, gx, gy; };
 
-__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f)
-{
-    const uint32_t q = __umulhi(f.magic, n);
-    const uint32_t t = ((n - q) >> 1) + q;
-    return f.one ? n : (t >> f.shift);
-}
 __device__ __forceinline__ uint32_t global_row(const RenderParams& rp, uint32_t ly)
 {
     const uint32_t strip = fastdiv(ly, rp.div_strip_rows);
     return (strip * rp.world_size + rp.rank) * rp.strip_rows + (ly - strip * rp.strip_rows);
 }
-__device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t pid)
+// path id <-> (batch-local sample, index of the pixel in the active rectangle): RenderParams::blk_log
+struct PidParts { uint32_t s, k; };
+__device__ __forceinline__ PidParts pid_split(const RenderParams& rp, uint32_t pid)
 {
-    const uint32_t s = fastdiv(pid, rp.div_act_pixels), k = pid - s * rp.act_pixels;
-    const uint32_t r = fastdiv(k, rp.div_act_w), x = rp.act_x0 + (k - r * rp.act_w);
+    const uint32_t b = fastdiv(pid, rp.div_blk_paths), rem = pid - b * (rp.act_pixels << rp.blk_log);
+    const bool short_blk = b + 1u == rp.n_blk;   // (the last block; blk_last == 1 << blk_log when it is a full one: both branches then agree)
+    const uint32_t k = short_blk ? fastdiv(rem, rp.div_blk_last) : (rem >> rp.blk_log);
+    return PidParts{(b << rp.blk_log) + (rem - k * (short_blk ? rp.blk_last : (1u << rp.blk_log))), k};
+}
+__device__ __forceinline__ uint32_t pid_join(const RenderParams& rp, uint32_t s, uint32_t k)
+{
+    const uint32_t b = s >> rp.blk_log;
+    return b * (rp.act_pixels << rp.blk_log) + k * (b + 1u == rp.n_blk ? rp.blk_last : (1u << rp.blk_log)) + (s - (b << rp.blk_log));
+}
+__device__ __forceinline__ PixelId path_pixel(const RenderParams& rp, uint32_t pid, uint32_t* s_local = nullptr, uint32_t* k_out = nullptr)
+{
+    const PidParts pp = pid_split(rp, pid);
+    if (s_local) *s_local = pp.s;
+    if (k_out) *k_out = pp.k;
+    const uint32_t r = fastdiv(pp.k, rp.div_act_w), x = rp.act_x0 + (pp.k - r * rp.act_w);
     const uint32_t ly = rp.act_ly0 + r;
     const uint32_t gy = global_row(rp, ly);
-    return PixelId{gy * rp.width + x, rp.first_sample + s, ly * rp.width + x, x, gy};
+    return PixelId{gy * rp.width + x, rp.first_sample + pp.s, ly * rp.width + x, x, gy};
 }
 
 // direction of the camera ray of (pixel gx, gy; sample): main.rs:193-199 + Camera::create_ray camera.rs:94-105
@@ -1683,12 +1700,13 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
                 const DInstance& in = sv.instances[inst];
                 if (bounce == 0u)                                                     // integrator.rs:181-185
                 {
-                    if (pid >= rp.keep_pos_from)
+                    const PidParts pp = pid_split(rp, pid);
+                    if (pp.s == rp.keep_s_pos)
                     {
                         const f3 p = fma3(xyz(rb), bc3(hit.x), xyz(ra));
-                        io.st.first_pos[pid - rp.keep_pos_from] = f4{p.x, p.y, p.z, hit.x};
+                        io.st.first_pos[pp.k] = f4{p.x, p.y, p.z, hit.x};
                     }
-                    if (pid >= rp.keep_id_from) io.st.first_id[pid - rp.keep_id_from] = in.blas & 0xffu;
+                    if (pp.s >= rp.keep_s_id) io.st.first_id[(pp.s - rp.keep_s_id) * rp.act_pixels + pp.k] = in.blas & 0xffu;
                 }
                 const DMaterial& m = sv.materials[in.material];
                 if (!rp.enable_nee || (flags & FLAG_LAST_DELTA) || bounce == 0u)       // integrator.rs:209-212
@@ -1794,12 +1812,13 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_WAVES) k_shade_surf
             bool front;
             const f3 normal = hit_normal(sv, inst, tri, hit.y, hit.z, rd, front);
             const f3 p = fma3(rd, bc3(hit.x), ro);                                     // r.at(hit_info.t)
+            uint32_t s_local, k_pix;
+            const PixelId px = path_pixel(rp, pid, &s_local, &k_pix);
             if (bounce == 0u)                                                          // integrator.rs:181-185
             {
-                if (pid >= rp.keep_pos_from) io.st.first_pos[pid - rp.keep_pos_from] = f4{p.x, p.y, p.z, hit.x};
-                if (pid >= rp.keep_id_from) io.st.first_id[pid - rp.keep_id_from] = in.blas & 0xffu;
+                if (s_local == rp.keep_s_pos) io.st.first_pos[k_pix] = f4{p.x, p.y, p.z, hit.x};
+                if (s_local >= rp.keep_s_id) io.st.first_id[(s_local - rp.keep_s_id) * rp.act_pixels + k_pix] = in.blas & 0xffu;
             }
-            const PixelId px = path_pixel(rp, pid);
             Stream rng{stream_key(rp.seed, px.gpixel, px.sample), asu(pw4.w)};
             const f3 wi = -rd;                                                         // integrator.rs:187
             const bool is_delta = mat_is_delta(mat.kind);
@@ -2096,9 +2115,10 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
             for (uint32_t j = 0; j < G; ++j)
             {
                 const uint32_t s = s0 + 4u * j + q;
-                oc[j] = s < rp.batch_samples ? (uint32_t)st.occl[s * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
+                const uint32_t pid = pid_join(rp, s, k);
+                oc[j] = s < rp.batch_samples ? (uint32_t)st.occl[pid] : (uint32_t)PRIMARY_MISS;
                 // (a primary miss's record is stale memory inside the allocation: read and dropped, so that the load need not wait for the byte)
-                rad[j] = s < rp.batch_samples ? st.radiance[s * rp.act_pixels + k] : f4{};
+                rad[j] = s < rp.batch_samples ? st.radiance[pid] : f4{};
             }
             f3 c[G];
 #pragma unroll
@@ -2119,11 +2139,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
             }
         }
         if (q != 0u) return;
-        // (id << 16) | new once per sample: only the batch's last two samples are kept (RenderParams::keep_id_from)
-        for (uint32_t s = rp.batch_samples >= 2u ? rp.batch_samples - 2u : 0u; s < rp.batch_samples; ++s)
+        // (id << 16) | new once per sample: only the batch's last two samples are kept (RenderParams::keep_s_id); a camera ray that left the
+        // scene at once wrote nothing but its PRIMARY_MISS byte: id 255 (integrator.rs:157)
+        for (uint32_t s = rp.keep_s_id; s < rp.batch_samples; ++s)
         {
-            const uint32_t pid = s * rp.act_pixels + k;
-            if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid - rp.keep_id_from];
+            const bool miss = st.occl[pid_join(rp, s, k)] == PRIMARY_MISS;
+            idv = (idv << 16) | (miss ? 255u : st.first_id[(s - rp.keep_s_id) * rp.act_pixels + k]);
         }
     }
     else
@@ -2134,24 +2155,33 @@ __global__ void __launch_bounds__(256) k_accumulate(const RenderParams rp, const
             uint32_t oc[G];
             f4 rad[G];
 #pragma unroll
-            for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[(s0 + j) * rp.act_pixels + k] : (uint32_t)PRIMARY_MISS;
+            for (uint32_t j = 0; j < G; ++j) oc[j] = (s0 + j) < rp.batch_samples ? (uint32_t)st.occl[pid_join(rp, s0 + j, k)] : (uint32_t)PRIMARY_MISS;
 #pragma unroll
-            for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[(s0 + j) * rp.act_pixels + k] : f4{0.006f, 0.006f, 0.006f, 0.0f};
+            for (uint32_t j = 0; j < G; ++j) rad[j] = oc[j] != PRIMARY_MISS ? st.radiance[pid_join(rp, s0 + j, k)] : f4{0.006f, 0.006f, 0.006f, 0.0f};
 #pragma unroll
             for (uint32_t j = 0; j < G; ++j)
             {
                 if ((s0 + j) >= rp.batch_samples) break;
-                const uint32_t pid = (s0 + j) * rp.act_pixels + k;
                 const f3 c = finalise(xyz(rad[j]));
                 a = f4{a.x + c.x, a.y + c.y, a.z + c.z, a.w + 1.0f};
-                // (id << 16) | new once per sample: only the last two samples survive in 32 bits
-                if (pid >= rp.keep_id_from) idv = (idv << 16) | st.first_id[pid - rp.keep_id_from];
+                // (id << 16) | new once per sample: only the last two samples survive in 32 bits; a PRIMARY_MISS is id 255 (integrator.rs:157)
+                if (s0 + j >= rp.keep_s_id) idv = (idv << 16) | (oc[j] == PRIMARY_MISS ? 255u : st.first_id[(s0 + j - rp.keep_s_id) * rp.act_pixels + k]);
             }
         }
     }
     if (add_to_accum) accum[lp] = a;
     id[lp] = idv;
-    if (write_position) position[lp] = st.first_pos[k]; // the batch's last sample: (batch_samples - 1) * act_pixels + k - keep_pos_from
+    if (write_position)
+    {
+        // the batch's last sample.  A camera ray that left the scene at once has no record: r.at(1e5) of that sample's ray (integrator.rs:156)
+        if (st.occl[pid_join(rp, rp.keep_s_pos, k)] == PRIMARY_MISS)
+        {
+            const f3 d = camera_ray_dir(rp, cam, x, global_row(rp, ly), rp.first_sample + rp.keep_s_pos);
+            const f3 far = fma3(d, bc3(1e5f), f3{cam.eye[0], cam.eye[1], cam.eye[2]});
+            position[lp] = f4{far.x, far.y, far.z, 1e5f};
+        }
+        else position[lp] = st.first_pos[k];
+    }
 }
 
 // per-sample radiance (pt_render_samples): out[sample * local_pixels + local pixel]
@@ -2164,7 +2194,7 @@ __global__ void __launch_bounds__(256) k_store_samples(const RenderParams rp, co
     f3 c{0.006f, 0.006f, 0.006f};
     if (x - rp.act_x0 < rp.act_w && ly - rp.act_ly0 < rp.act_rows)
     {
-        const uint32_t pid = s * rp.act_pixels + (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0);
+        const uint32_t pid = pid_join(rp, s, (ly - rp.act_ly0) * rp.act_w + (x - rp.act_x0));
         c = finalise(st.occl[pid] == PRIMARY_MISS ? f3{0.006f, 0.006f, 0.006f} : xyz(st.radiance[pid]));
     }
     out[i] = f4{c.x, c.y, c.z, 1.0f};
@@ -2318,8 +2348,9 @@ void launch_trace_world(hipStream_t s, const TraceLaunch& tl, const WavefrontBuf
         out.occl = wb.st.occl;
         out.first_pos = wb.st.first_pos;
         out.first_id = wb.st.first_id;
-        out.keep_id_from = rp.keep_id_from;
-        out.keep_pos_from = rp.keep_pos_from;
+        out.keep_s_id = rp.keep_s_id; out.keep_s_pos = rp.keep_s_pos;
+        out.blk_log = rp.blk_log; out.n_blk = rp.n_blk; out.blk_last = rp.blk_last; out.act_pixels = rp.act_pixels;
+        out.div_blk_paths = rp.div_blk_paths; out.div_blk_last = rp.div_blk_last;
         out.finalize_miss = env.w == 0u ? 1u : 0u;
         launch_closest_impl<CLOSEST_PRIMARY>(s, tl, tl.scene.world_root, wb.rq[0], &row->n_closest, wb.cap_slots, row_heads(wb, b, HEADS_CLOSEST), out);
     }

@@ -173,16 +173,22 @@ struct RenderParams
     uint32_t batch_samples;
     uint32_t n_paths;        // act_pixels * batch_samples
     uint32_t max_bounces, n_sobol, enable_nee;
-    uint32_t keep_id_from;   // path ids >= this belong to the batch's last two samples (id history, main.rs:206)
-    uint32_t keep_pos_from;  // path ids >= this belong to the batch's last sample (first-hit position, main.rs:205)
+    uint32_t keep_s_id;      // batch-local samples >= this are the batch's last two: their first-hit id is kept (id history, main.rs:206)
+    uint32_t keep_s_pos;     // the batch's last sample (batch_samples - 1): its first-hit position is kept (main.rs:205)
+    // PATH IDS are dealt in BLOCKS of 2^blk_log samples: block b holds samples [b << blk_log, ...) of every active pixel, and inside a block the
+    // samples of ONE pixel are consecutive:  pid = b * (act_pixels << blk_log) + k * (samples in block b) + (sample - (b << blk_log)),  k = the pixel's index
+    // in the active rectangle (row-major).  64 consecutive path ids — what a traversal wave fetches — are then 2^blk_log samples of 64 >> blk_log
+    // neighbouring pixels instead of one sample of 64 pixels in a row: camera rays eight times closer together, and the shadow rays of a bounce-0 hit
+    // leave one point for one light.  blk_log = 0 is the sample-major order of rounds 1-3.  The batch's last block may be short (blk_last samples).
+    uint32_t blk_log, n_blk, blk_last;
     // Camera rays are generated only for the ACTIVE pixels: a rectangle of columns [act_x0, act_x0 + act_w) and LOCAL rows
     // [act_ly0, act_ly0 + act_rows) outside which every camera ray provably misses the scene's bounds (the host projects the world
     // TLAS's root box onto the image plane, with a margin; pt_api.cpp).  Path id = sample * act_pixels + (row - act_ly0) * act_w +
-    // (column - act_x0); pixels outside the rectangle get the miss result (integrator.rs:263-266) in k_accumulate.
+    // (column - act_x0) in round 1-3's sample-major order (now: pid_join); pixels outside the rectangle get the miss result (integrator.rs:263-266) in k_accumulate.
     uint32_t act_x0, act_w, act_ly0, act_rows, act_pixels;
-    uint32_t pad[2];
+    uint32_t pad[1];
     uint64_t seed;
-    FastDiv div_act_pixels, div_act_w, div_width, div_strip_rows;
+    FastDiv div_blk_paths, div_blk_last, div_act_w, div_width, div_strip_rows; // div_blk_paths: by act_pixels << blk_log
 };
 
 // wavefront state, one slot per path (pid = s_local * local_pixels + local_pixel).  What a shading pass reads and writes together is
@@ -207,8 +213,8 @@ struct PathState
     uint8_t* occl;
     uint32_t* vstack;   // volume stack (integrator.rs:161): four material indices, one per byte, 0xff = empty, insertion order; null without volumes
     f4* radiance;       // finished paths: accumulated.xyz (what integrate() returns before the finite check), dense by path id
-    f4* first_pos;      // first-hit xyz | t        (main.rs:205) of the batch's LAST sample: index = path id - keep_pos_from
-    uint32_t* first_id; // of the batch's last TWO samples (id history, main.rs:206): index = path id - keep_id_from
+    f4* first_pos;      // first-hit xyz | t        (main.rs:205) of the batch's LAST sample (RenderParams::keep_s_pos): index = the pixel's index in the active rectangle
+    uint32_t* first_id; // of the batch's last TWO samples (id history, main.rs:206): index = (sample - keep_s_id) * act_pixels + pixel index
 };
 enum : uint32_t { FLAG_BOUNCE_MASK = 0xffffu, FLAG_LAST_DELTA = 1u << 16, FLAG_NEE_PENDING = 1u << 17, FLAG_BSDF_CAST = 1u << 18 };
 

@@ -40,20 +40,23 @@ namespace {
 #ifndef PT_REFILL_BELOW_ANY
 #define PT_REFILL_BELOW_ANY PT_REFILL_BELOW
 #endif
-// waves per SIMD the compiler must leave room for in the traversal kernels (second parameter of __launch_bounds__).  BVH in LDS: 4 for
-// both (3 / 5 / 2: within noise).  BVH in global memory: 5 for both.  The kernels wait on L2 — one more DEPENDENT load per branch level,
-// an L1 hit, costs the closest-hit kernel 10-13 % (experiments/r04_latency_probe.patch, round 4) — so a fifth wave pays, provided it is not bought
-// with scratch: round 2 asked the compiler for 5 or 6 waves of the kernel as it was (123-127 VGPRs wanted: 72-164 B of scratch) and got
-// +-0 / -15 %; round 4 first took the register peak away — the closest-hit leaves of these kernels test ONE triangle at a time instead of
-// two side by side (PT_PAIR_LEAVES_GLOBAL = 0: 123 -> 105 VGPRs) — and then 96 VGPRs cost 8-12 B of scratch.  Same-box A/B, whole frame
-// at 64 spp, atrium / 82 k mesh / 328 k mesh / spheres: pairs at 4 waves 325 / 73.6 / 123.5 / 54.4 ms, single at 4 waves 309 / 70.1 /
-// 119.6 / 52.9, single at 5 waves 281 / 67.2 / 115.0 / 49.6 (-14 / -9 / -7 / -9 %); 6 waves (80 VGPRs, 64-88 B of scratch, 13 stack
-// levels in LDS) 315 / 71.7 / 124.0 / 54.4; any-hit alone at 6: 295 / 68.3 / 114.7 / 51.4.
+// waves per SIMD the compiler must leave room for in the traversal kernels (second parameter of __launch_bounds__): FIVE, for every variant.
+// BVH in global memory: the kernels wait on L2 — one more DEPENDENT load per branch level, an L1 hit, costs the closest-hit kernel 10-13 %
+// (experiments/r04_latency_probe.patch, round 4) — so a fifth wave pays, provided it is not bought with scratch: round 2 asked the compiler for 5 or
+// 6 waves of the kernel as it was (123-127 VGPRs wanted: 72-164 B of scratch) and got +-0 / -15 %; round 4 first took the register peak away — the
+// closest-hit leaves test ONE triangle at a time instead of two side by side (123 -> 105 VGPRs) — and then 96 VGPRs cost 8-20 B of scratch, all of it
+// in the service sections.  Same-box A/B, whole frame at 64 spp, atrium / 82 k mesh / 328 k mesh / spheres: pairs at 4 waves 325 / 73.6 / 123.5 / 54.4 ms,
+// single at 4 waves 309 / 70.1 / 119.6 / 52.9, single at 5 waves 281 / 67.2 / 115.0 / 49.6 (-14 / -9 / -7 / -9 %); 6 waves (80 VGPRs, 64-88 B of
+// scratch, 13 stack levels in LDS) 315 / 71.7 / 124.0 / 54.4; any-hit alone at 6: 295 / 68.3 / 114.7 / 51.4.
+// BVH in LDS: these kernels run at 0.80-0.87 of VALU issue at four waves, and the same change fills most of the rest: Cornell 256 spp 66.3 -> 61.4 ms,
+// its 1/8 share 10.1 -> 9.4 ms, mixed materials 77.4 -> 72.2 ms (k_trace_fused then carries 48 B of scratch).  Pairs at five waves 63.3 / 9.55 / 74.8; single
+// at four 65.1 / 10.1 / 75.6; closest-hit four + any-hit five 64.5 / 9.7 / 74.7; closest-hit five + any-hit six 62.9 / 9.5 / 74.5; six for both 66.4 / 10.0 / 77.3;
+// world + NEE launches unfused at five 62.1 / 9.5 / 73.5.
 #ifndef PT_WAVES_LDS_BVH
-#define PT_WAVES_LDS_BVH 4
+#define PT_WAVES_LDS_BVH 5
 #endif
 #ifndef PT_WAVES_LDS_BVH_ANY
-#define PT_WAVES_LDS_BVH_ANY 4
+#define PT_WAVES_LDS_BVH_ANY 5
 #endif
 #ifndef PT_WAVES_GLOBAL_BVH
 #define PT_WAVES_GLOBAL_BVH 5
@@ -75,11 +78,6 @@ namespace {
 // PT_STEP_STATS (variant builds, tools/step_stats.py): per traversal step of k_closest, how many lanes take each section
 #ifndef PT_STEP_STATS
 #define PT_STEP_STATS 0
-#endif
-// closest-hit leaves of BVHs in global memory: two triangles side by side (as the LDS scenes do: -2.2 ms per Cornell frame) or one at a
-// time (18 VGPRs fewer, which is what lets these kernels run five waves per SIMD: see PT_WAVES_GLOBAL_BVH)
-#ifndef PT_PAIR_LEAVES_GLOBAL
-#define PT_PAIR_LEAVES_GLOBAL 0
 #endif
 // PT_WAVE_TIMES (variant builds, tools/wave_times.py): when the waves of a k_closest launch start, first have rays, find the queue empty, end
 #ifndef PT_WAVE_TIMES
@@ -1141,8 +1139,8 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
             {
                 uint32_t first, count;
                 leaf_range(bl, kind, payload, first, count);
-                // blas.rs:230-251, two triangles at a time (a quad is the commonest leaf): both are evaluated side by side, then
-                // accepted in leaf order, the second against the t_max the first may have lowered
+                // blas.rs:230-251, in leaf order, each triangle against the t_max the one before may have lowered.  (Rounds 1-3 evaluated two triangles
+                // side by side — -2.2 ms per Cornell frame at four waves per SIMD — which cost 18 VGPRs; without it the kernels fit five waves: round 4.)
                 const f3 mo = fma3(ob.d, bc3(t_est), ob.o);  // ray.at(t_estimate)  primitive.rs:150
                 const float t_min = PT_EPSILON - t_est;
                 auto accept = [&](const TriEval& e, uint32_t tri) {
@@ -1157,17 +1155,7 @@ __device__ __forceinline__ void closest_body(const SceneView& sv, const Blob& bl
                         bid = (inst << prim_bits) | tri;
                     }
                 };
-                uint32_t k = 0;
-                if (LDS_SCENE || PT_PAIR_LEAVES_GLOBAL)
-                for (; k + 1u < count; k += 2u)
-                {
-                    const uint4* tp = bl.tris + 3u * (first + k);
-                    const TriEval ea = tri_eval(tp, mo, ob.d), eb = tri_eval(tp + 3, mo, ob.d);
-                    accept(ea, first + k);
-                    accept(eb, first + k + 1u);
-                }
-                if (LDS_SCENE || PT_PAIR_LEAVES_GLOBAL) { if (k < count) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k); }
-                else for (; k < count; ++k) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
+                for (uint32_t k = 0; k < count; ++k) accept(tri_eval(bl.tris + 3u * (first + k), mo, ob.d), first + k);
                 if (bt != bt) { sp = stk.empty(); in_blas = false; } // NaN t_max: nothing else can be accepted anywhere
             }
         }

@@ -43,7 +43,7 @@ using namespace pt;
 #define PT_SPLIT_MIN_PATHS (~0ull) // BVHs in global memory: a request that fits is no longer cut in two for two pipelines (round 4; see render_common)
 #endif
 #ifndef PT_SPLIT_MIN_PATHS_LDS
-#define PT_SPLIT_MIN_PATHS_LDS (100u << 20)
+#define PT_SPLIT_MIN_PATHS_LDS (24u << 20)
 #endif
 #ifndef PT_PIPES4_MIN_PATHS
 #define PT_PIPES4_MIN_PATHS (~0ull) // four pipelines by default: never (see render_common); pt_config.pipelines = 4 asks for them
@@ -933,6 +933,9 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     // 573 -> 588 ms, 328 k mesh at 1024 spp 1979 -> 1959 ms, three spheres at 4096^2 x 1024 spp 12.15 -> 12.43 s; off.
     const uint64_t total_paths = (uint64_t)n_samples * act_pixels;
     if (!samples_out && !c->cfg.pipelines && !c->lds_scene && total_paths >= (uint64_t)PT_PIPES4_MIN_PATHS) want_pipes = (uint32_t)pt_ctx::kMaxPipes;
+    // (Round 4: with five waves per SIMD in the traversal AND the surface shading kernels one pipeline's shading pass runs beside the other's traversal, and the split pays
+    // from a quarter of the headline frame on: whole frame 62.4 -> 59.0 ms, rank 0's half 32.4 -> 30.5, its quarter 17.1 -> 16.4, its eighth (16.6 M paths) 9.44 -> 9.38:
+    // from PT_SPLIT_MIN_PATHS_LDS = 24 M paths on.)  Round 3:
     // LDS-resident BVHs gain only on very large requests (with round 3's launch structure): the 133 M-path headline frame 68.3 -> 67.2 ms
     // (bench.py, three interleaved repeats), mixed materials at 66 M paths 42.9 -> 42.3 ms, but rank 0's half of the sharded frame (66 M
     // paths) 35.0 -> 35.7 ms and its quarter +-0: from PT_SPLIT_MIN_PATHS_LDS paths on.

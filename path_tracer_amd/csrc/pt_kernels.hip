@@ -111,9 +111,27 @@ namespace {
 #define PT_CLAIM_AHEAD 0 // rays left in a chunk when the next one is claimed; 0 = as soon as the chunk is taken up (same-box A/B of 64 / 128 / 256: +0.3 ms for a 1/8 share, +3 ms per frame)
 #endif
 // threads per shading workgroup (a workgroup makes one reservation per queue and iteration: block_append4)
+// waves per SIMD the surface shading kernels must leave room for (1: whatever the registers they want allow — 102-130 VGPRs: four, GGX with volumes three).
+// Five: the Lambertian kernel fits 96 VGPRs without scratch.  Round 3 measured that at FOUR traversal waves: the pass's own launches 22.39 -> 22.26 ms, the
+// two-pipeline frame +1 ms.  Round 4, traversal kernels at five waves: one pipeline 62.35 -> 62.63 ms (nothing), but the default two-pipeline frame
+// 61.2 -> 59.0 ms and mixed materials 72.8 -> 70.0 ms: the fifth wave lets one pipeline's shading pass run beside the other's traversal.  Six (80 VGPRs, 60 B
+// of scratch): 64.4 / 76.0 ms.
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 1 // waves per SIMD the surface shading kernels must leave room for (1: whatever the registers they want allow)
+#define PT_SHADE_WAVES 5
 #endif
+#ifndef PT_SHADE_WAVES_DIEL
+#define PT_SHADE_WAVES_DIEL 5   // (16 B of scratch)
+#endif
+#ifndef PT_SHADE_WAVES_GGX
+#define PT_SHADE_WAVES_GGX 5    // (64 B of scratch, and still better than four waves: mixed materials 71.5 -> 70.3 ms)
+#endif
+#ifndef PT_SHADE_WAVES_VOLUMES
+#define PT_SHADE_WAVES_VOLUMES 4 // kernels of scenes with participating media (five: 32-104 B of scratch; media scene 47.2 -> 48.7 ms)
+#endif
+constexpr int shade_waves(uint32_t qclass, bool volumes)
+{
+    return volumes ? PT_SHADE_WAVES_VOLUMES : (qclass == Q_GGX ? PT_SHADE_WAVES_GGX : (qclass == Q_DIELECTRIC ? PT_SHADE_WAVES_DIEL : PT_SHADE_WAVES));
+}
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
@@ -1722,7 +1740,7 @@ __device__ __forceinline__ const ShadeKArgs& shade_args()
     [[maybe_unused]] const RenderParams& rp = ka_.rp;                                                                              \
     [[maybe_unused]] const ShadeIO& io = ka_.io;
 template <uint32_t QCLASS, bool VOLUMES>
-__global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_WAVES) k_shade_surface(const ShadeKArgs kargs)
+__global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)) k_shade_surface(const ShadeKArgs kargs)
 {
     // Only what the loop header needs is taken from the argument here; each section of an iteration re-reads the launch description from
     // the kernel-argument segment (PT_SHADE_ARGS: scalar loads that hit the constant cache) instead of keeping ~130 words of it in ~100

@@ -40,7 +40,7 @@ using namespace pt;
 #define PT_SIDE_PRIORITY 0
 #endif
 #ifndef PT_SPLIT_MIN_PATHS
-#define PT_SPLIT_MIN_PATHS (~0ull) // BVHs in global memory: a request that fits is no longer cut in two for two pipelines (round 4; see render_common)
+#define PT_SPLIT_MIN_PATHS (24u << 20) // BVHs in global memory: a request that fits is cut in two for two pipelines from this many paths on (see render_common)
 #endif
 #ifndef PT_SPLIT_MIN_PATHS_LDS
 #define PT_SPLIT_MIN_PATHS_LDS (24u << 20)
@@ -928,8 +928,11 @@ int render_common(pt_ctx* c, uint32_t first_sample, uint32_t n_samples, float* s
     //   8 spp (4 M paths) 14.21 -> 14.26: nothing; three spheres, 8 spp (7.8 M paths): 10.46 -> 9.95 (four pipelines: 11.3)
     // so (rounds 2-3, FOUR waves per SIMD): two pipelines from 6 M paths on.  Round 4, FIVE waves per SIMD — the kernels hide more of their own latency, a second
     // persistent grid has less to fill — same box, one pipeline against the split: 82 k mesh 64 spp 67.2 -> 64.9 ms, 512 spp 497 -> 475; 328 k mesh 64 spp 115.1 -> 113.5,
-    // 1024 spp (bench.py) 1663 -> 1637; atrium 256 spp 1127-1141 -> 1112-1114, but 64 spp 280.7 -> 288.2 and 8 spp 38.7 -> 39.5; spheres +-0: the split is off
-    // (PT_SPLIT_MIN_PATHS).  Four (from PT_PIPES4_MIN_PATHS on) did not hold up under bench.py: 82 k mesh at 512 spp
+    // 1024 spp (bench.py) 1663 -> 1637; atrium 256 spp 1127-1141 -> 1112-1114, but 64 spp 280.7 -> 288.2 and 8 spp 38.7 -> 39.5; spheres +-0: the split went off ...
+    // ... and came back once the surface shading kernels ran at five waves too (one pipeline's shading beside the other's traversal), same box, one batch against
+    // two halves: atrium 16 / 64 spp 74.1 -> 71.8 / 281.6 -> 272.7 ms, 82 k mesh 16 / 64 spp 20.4 -> 20.3 / 64.7 -> 62.7, 328 k mesh 64 spp 113.5 -> 108.6, three spheres
+    // 16 / 64 spp 15.1 -> 15.2 / 49.4 -> 47.7: from PT_SPLIT_MIN_PATHS = 24 M paths on, as for LDS scenes.  (Requests that do not fit always alternated between two
+    // pipelines.)  Four (from PT_PIPES4_MIN_PATHS on) did not hold up under bench.py: 82 k mesh at 512 spp
     // 573 -> 588 ms, 328 k mesh at 1024 spp 1979 -> 1959 ms, three spheres at 4096^2 x 1024 spp 12.15 -> 12.43 s; off.
     const uint64_t total_paths = (uint64_t)n_samples * act_pixels;
     if (!samples_out && !c->cfg.pipelines && !c->lds_scene && total_paths >= (uint64_t)PT_PIPES4_MIN_PATHS) want_pipes = (uint32_t)pt_ctx::kMaxPipes;

@@ -96,15 +96,15 @@ def main(src, tag):
         # world closest-hit launches: k_closest<.., WORLD = 0 | PRIMARY = 3, ..> and k_trace_fused (bounces >= 1 of LDS scenes: world closest hit + the few BSDF-sampled NEE rays)
         keys = [k for k in traffic if re.match(r"k_closest\d?<\w+, [03](, \w+)*>$", k) or k.startswith("k_trace_fused")]
         tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches"] for k in keys)
-        # resident waves per SIMD of the traversal kernels: 4 with the BVH in LDS (111-117 VGPRs), 5 with it in global memory (96 VGPRs since round 4)
-        waves = 4 if pmc_bench["config"].get("bvh_in_lds", True) else 5
+        # resident waves per SIMD of the traversal kernels: 5 (92-96 VGPRs under __launch_bounds__(256, 5) since round 4, BVH in LDS or in global memory; rounds 1-3: 4)
+        waves = 5
         va = sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys) / sum(g.loc[k, "SQ_WAVE_CYCLES"] for k in keys)
         ln = sum(g.loc[k, "SQ_THREAD_CYCLES_VALU"] for k in keys) / sum(g.loc[k, "SQ_ACTIVE_INST_VALU"] for k in keys)
         traffic["k_closest_world"] = {"kernels": keys, "rays": rays, "hbm_bytes": tot, "hbm_bytes_per_ray": tot / rays, "spp": spp_p,
                                       "valu_active_frac": va, "lanes_per_valu_instr": ln, "waves_per_simd": waves,
                                       "algorithmic_bytes_per_ray": pmc_bench["roofline"].get("algorithmic_bytes_per_ray"),
                                       "note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as read; valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a "
-                                              "wave's lifetime it issues VALU; x waves_per_simd = VALU busy: 4 waves per SIMD resident with the BVH in LDS, 5 with it in global memory), "
+                                              "wave's lifetime it issues VALU; x waves_per_simd = VALU busy: 5 waves per SIMD resident since round 4), "
                                               "lanes_per_valu_instr = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
         lines += ["", f"k_closest PRIMARY+WORLD: VALU-active share of wave lifetime {va:.3f} (x {waves} resident waves per SIMD = {waves * va:.2f} VALU busy); lanes active per VALU instruction {ln:.1f} of 64 "
                   f"(effective VALU use {waves * va * ln / 64:.2f}).",

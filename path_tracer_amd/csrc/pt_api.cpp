@@ -641,6 +641,7 @@ struct BatchRun
     hipStream_t s = nullptr;
     uint32_t rows = 0, shade_blocks = 1, last_row = 0, count = 0, cleared_rows = 0;
     bool nee = false, side_busy = false, stopped = false, write_position = false, aux_with_samples = false, fused = false;
+    bool no_shadow_queue = false; // every shadow ray of the scene is answered inside the shading pass (shade_traces_shadow): launch_trace_shadow has nothing to do
     int nee_err = PT_OK;
     f4* samples_out = nullptr;
     hipEvent_t after = nullptr;
@@ -723,6 +724,8 @@ int batch_begin(BatchRun& br, pt_ctx* c, int pipe, uint32_t first_sample, uint32
     // frame 1.24 -> 1.18 ms; BVHs in global memory lose 3 % (82 k mesh 14.2 -> 14.65 ms, 328 k 25.4 -> 26.3 ms: their NEE rays are long and
     // used to overlap the shadow-ray launch), so only the former.  Per-launch event timing (PT_FLAG_TIMING_ALL) keeps the launches apart.
     br.fused = PT_FUSED_TRACE != 0 && c->lds_scene && !(g.flags & PT_FLAG_TIMING_ALL);
+    // the Lambertian shading pass of an LDS-resident scene walks its own shadow rays; GGX surfaces (the only other class that casts them) still queue theirs
+    br.no_shadow_queue = shade_traces_shadow(br.tl) && !c->class_present[Q_GGX];
     return PT_OK;
 }
 
@@ -740,7 +743,7 @@ void batch_nee_launches(BatchRun& br, uint32_t row)
     // cross-stream event waits: its two launches go out one after the other
     if (timing_all || br.rp.n_paths < (uint32_t)PT_SIDE_MIN_PATHS)
     {
-        { Timer t(c, pp, br.s, T_ANY); launch_trace_shadow(br.s, br.tl, wb, row); }
+        if (!br.no_shadow_queue) { Timer t(c, pp, br.s, T_ANY); launch_trace_shadow(br.s, br.tl, wb, row); }
         { Timer t(c, pp, br.s, T_LIGHT); launch_trace_lchain(br.s, br.tl, wb, row); }
         return;
     }
@@ -748,7 +751,7 @@ void batch_nee_launches(BatchRun& br, uint32_t row)
     launch_trace_lchain(pp.side_stream, br.tl_side, wb, row);
     if (hipEventRecord(pp.ev_join, pp.side_stream) != hipSuccess) br.nee_err = PT_ERR_HIP;
     br.side_busy = true;
-    launch_trace_shadow(br.s, br.tl, wb, row);
+    if (!br.no_shadow_queue) launch_trace_shadow(br.s, br.tl, wb, row);
 }
 
 void batch_join_side(BatchRun& br)
@@ -777,7 +780,7 @@ int batch_bounce(BatchRun& br, uint32_t b)
     if (b > 0 && br.nee && br.fused)
     {
         // the shadow rays of the bounce before, then ONE launch for this bounce's world closest hit and the bounce before's BSDF-sampled NEE rays
-        { Timer t(c, pp, s, T_ANY); launch_trace_shadow(s, br.tl, wb, b - 1); }
+        if (!br.no_shadow_queue) { Timer t(c, pp, s, T_ANY); launch_trace_shadow(s, br.tl, wb, b - 1); }
         Timer t(c, pp, s, T_WORLD);
         launch_trace_fused(s, br.tl, wb, b, br.rp, br.env);
     }
@@ -791,7 +794,7 @@ int batch_bounce(BatchRun& br, uint32_t b)
         batch_join_side(br);
     }
     for (uint32_t q = 0; q < Q_COUNT; ++q)
-        if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, br.rp, wb, b, br.shade_blocks, br.cam, br.env); }
+        if (c->class_present[q]) { Timer t(c, pp, s, T_SHADE); launch_shade(s, q, c->sv, br.rp, wb, b, br.shade_blocks, br.cam, br.env, &br.tl); }
     // long bounce budgets (reference default MAX_BOUNCES = 1024): stop once no path is left
     if (g.max_bounces > 16 && b >= 8 && (b % 4) == 0 && b < g.max_bounces)
     {

@@ -69,8 +69,11 @@ void launch_trace_shadow(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
 // BSDF-sampled NEE rays: closest hit against the lights TLAS, then (same kernel, same lane) any-hit against the world
 void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBuffers& wb, uint32_t b);
 // shading of bounce b for one queue class
+// (tl: the scene's traversal launch description; with it the Lambert / GGX passes of an LDS-resident scene may trace their own shadow rays)
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env);
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env, const TraceLaunch* tl = nullptr);
+// true: the shading pass answers the explicit-light shadow rays itself and nothing is queued for launch_trace_shadow
+bool shade_traces_shadow(const TraceLaunch& tl);
 // accum[pixel] += sum over batch samples in order of (finalised rgb, 1); position/id of the last samples
 void launch_accumulate(hipStream_t s, const RenderParams& rp, const CameraView& cam, const WavefrontBuffers& wb, f4* accum, f4* position, uint32_t* id,
                        uint32_t write_position, uint32_t add_to_accum);

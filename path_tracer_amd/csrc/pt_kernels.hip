@@ -132,6 +132,13 @@ constexpr int shade_waves(uint32_t qclass, bool volumes)
 {
     return volumes ? PT_SHADE_WAVES_VOLUMES : (qclass == Q_GGX ? PT_SHADE_WAVES_GGX : (qclass == Q_DIELECTRIC ? PT_SHADE_WAVES_DIEL : PT_SHADE_WAVES));
 }
+// LDS-resident scenes: the shading pass traces its explicit-light shadow ray itself (inline_any) instead of queueing it for k_any<SHADOW>
+#ifndef PT_INLINE_SHADOW
+#define PT_INLINE_SHADOW 1
+#endif
+#ifndef PT_SHADE_WAVES_INLINE
+#define PT_SHADE_WAVES_INLINE 5
+#endif
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
@@ -1596,6 +1603,7 @@ struct ShadeIO
     uint32_t cap_slots, cap_slots_term, cap_slots_shade; // queue capacities (slots)
     Counters* ctr;     // row of this bounce
     uint32_t* lchain_heads; // cursor lines of this bounce's BSDF-sampled NEE queue (the culled tally goes there)
+    uint32_t* shadow_heads; // cursor lines of this bounce's shadow-ray queue (INLINE: the tally of shadow rays traced by the shading pass itself)
     Counters* ctr_next;
     f4 primary_a;      // bounce 0: origin.xyz | +inf of every primary ray
     EnvView env;       // equirect environment for misses (w == 0: constant ambient, integrator.rs:263-266)
@@ -1723,10 +1731,97 @@ __global__ void __launch_bounds__(256) k_shade_terminal(const SceneView sv, cons
     }
 }
 
+// TLAS::any_intersect for ONE ray per lane, run by the whole wave until its last ray is done (no refill): the shading pass of an LDS-resident scene
+// answers its own explicit-light shadow ray with it (k_shade_surface<.., INLINE>).  Steps as in any_body: a node's box is tested when its parent is
+// expanded, only nodes that were met go on the stack; the answer is a disjunction, so the order cannot change it.
+__device__ __forceinline__ bool inline_any(const Blob& bl, const Stack8<false>& stk, const uint32_t root, const f4 ra, const f4 rb, const bool want)
+{
+    bool active = false, blocked = false, in_blas = false, ray_finite = false;
+    LaneRay w{}, ob{};
+    const float t_max = ra.w;
+    uint32_t sp = stk.empty(), blas_base = 0u;
+    if (want)
+    {
+        w.o = xyz(ra);
+        w.d = xyz(rb);
+        w.inv = rcp3(w.d);
+        ray_finite = finite3(w.o) && finite3(w.d);
+        float te;
+        const uint4 root0 = bl.nodes[2u * root];
+        if ((t_max == t_max) && slab(root0, bl.nodes[2u * root + 1u], w.o, w.inv, t_max, te))
+        {
+            stk.put(sp, make_uint2(root0.w, asu(te)));
+            sp = stk.up(sp);
+            active = true;
+        }
+    }
+    while (__ballot(active) != 0ull)
+    {
+        if (!active) continue;
+        if (in_blas && sp == blas_base) in_blas = false;
+        if (sp == stk.empty()) { active = false; continue; }
+        sp = stk.down(sp);
+        const uint2 e = stk.get(sp);
+        uint32_t link = e.x;
+        float t_enter = asf(e.y);
+        if ((link >> NODE_KIND_SHIFT) == NODE_INSTANCE)
+        {
+            uint4 r0, r1;
+            ob = to_object<false, true>(bl, link & NODE_PAYLOAD_MASK, w, ray_finite, r0, r1);
+            in_blas = true;
+            blas_base = sp;
+            if (!slab(r0, r1, ob.o, ob.inv, t_max, t_enter)) continue;
+            link = r0.w;
+        }
+        uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
+#pragma unroll 1
+        for (int lvl = 0; lvl < PT_BRANCH_LEVELS_ANY && kind == NODE_BRANCH; ++lvl)
+        {
+            const uint4* cp = bl.nodes + 2u * payload;
+            const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
+            const f3 o = in_blas ? ob.o : w.o, inv = in_blas ? ob.inv : w.inv;
+            float tl, tr;
+            const bool hl = slab(l0, l1, o, inv, t_max, tl);
+            const bool hr = slab(r0, r1, o, inv, t_max, tr);
+            if (hl && hr) { stk.put(sp, make_uint2(l0.w, asu(tl))); sp = stk.up(sp); }
+            kind = NODE_INSTANCE;
+            if (hl || hr)
+            {
+                const uint2 next = hr ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
+                const uint32_t nk = next.x >> NODE_KIND_SHIFT;
+                if ((nk & 1u) != 0u || (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS_ANY))
+                {
+                    kind = nk;
+                    payload = next.x & NODE_PAYLOAD_MASK;
+                    t_enter = asf(next.y);
+                }
+                else { stk.put(sp, next); sp = stk.up(sp); }
+            }
+        }
+        if (kind & 1u)
+        {
+            uint32_t first, count;
+            leaf_range(bl, kind, payload, first, count);
+            for (uint32_t k = 0; k < count; ++k)
+            {
+                const uint4* tp = bl.tris + 3u * (first + k);
+                float td, ud, vd, det;
+                if (tri_planes(tp[0], tp[1], tp[2], ob.o, ob.d, t_max, t_enter, td, ud, vd, det))
+                {
+                    active = false;
+                    blocked = true;
+                    break;
+                }
+            }
+        }
+    }
+    return blocked;
+}
+
 // Surface classes.  One kernel per queue class; RNG draws in program order of integrator.rs:231-251.
 // The launch description as ONE kernel argument (offset 0 of the kernel-argument segment), so that a section of the kernel can read its
 // fields from there when it runs (shade_args) instead of holding them in scalar registers across the whole iteration.
-struct ShadeKArgs { SceneView sv; RenderParams rp; ShadeIO io; uint32_t bounce; };
+struct ShadeKArgs { SceneView sv; RenderParams rp; ShadeIO io; uint32_t bounce; const uint4* gblob; uint32_t world_root; };
 typedef const __attribute__((address_space(4))) ShadeKArgs* ShadeKArgsPtr;
 __device__ __forceinline__ const ShadeKArgs& shade_args()
 {
@@ -1739,9 +1834,10 @@ __device__ __forceinline__ const ShadeKArgs& shade_args()
     [[maybe_unused]] const SceneView& sv = ka_.sv;                                                                                 \
     [[maybe_unused]] const RenderParams& rp = ka_.rp;                                                                              \
     [[maybe_unused]] const ShadeIO& io = ka_.io;
-template <uint32_t QCLASS, bool VOLUMES>
-__global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)) k_shade_surface(const ShadeKArgs kargs)
+template <uint32_t QCLASS, bool VOLUMES, bool INLINE = false>
+__global__ void __launch_bounds__(PT_SHADE_THREADS, INLINE ? PT_SHADE_WAVES_INLINE : shade_waves(QCLASS, VOLUMES)) k_shade_surface(const ShadeKArgs kargs)
 {
+    extern __shared__ uint4 smem_dyn[];
     // Only what the loop header needs is taken from the argument here; each section of an iteration re-reads the launch description from
     // the kernel-argument segment (PT_SHADE_ARGS: scalar loads that hit the constant cache) instead of keeping ~130 words of it in ~100
     // scalar registers for the whole iteration: spilled scalars 81 -> 0 (every class), static VALU 1947 -> 1747 (no v_readlane / v_writelane).
@@ -1763,7 +1859,10 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)
             if (blockIdx.x == 0u) io.ctr->n_shade[QCLASS] = ext; // for the host's per-bounce table only
         }
     }
-    __syncthreads();
+    // INLINE: the BVH blob and the per-lane stacks in dynamic LDS, as in the traversal kernels (stage_scene ends with the barrier)
+    if (INLINE) { uint32_t words; (void)stage_scene<true>(kargs.sv, kargs.gblob, smem_dyn, words); }
+    else __syncthreads();
+    uint32_t traced = 0u; // INLINE: wave-uniform (a scalar register): shadow rays this wave has answered
     const uint32_t n = sh_extent;
     const uint32_t total = ((n + blockDim.x - 1u) / blockDim.x) * blockDim.x; // whole blocks take part in the queue appends
     uint32_t culled = 0;
@@ -1777,7 +1876,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)
     for (; idx < total; idx += stride)
     {
         const f4 rb = a_next;
-        a_next = (idx + stride) < n ? nt_load(io.q_in.a + idx + stride) : hole_a;
+        if (!INLINE) a_next = (idx + stride) < n ? nt_load(io.q_in.a + idx + stride) : hole_a; // (INLINE: requested after the shadow walk, which wants the registers)
         bool valid = idx < n && stripe_valid(sh_tail, stripes, idx) && asu(rb.w) != HOLE;
         bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
@@ -1977,7 +2076,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)
                             lc_b = f4{dir.x, dir.y, dir.z, asf(pid)};
                             flags |= FLAG_BSDF_CAST;
                         }
-                        else culled += 1u;
+                        else if (!INLINE) culled += 1u;
+                        if (INLINE) culled += (uint32_t)__popcll(__ballot(!may_hit)); // (wave-uniform count in a scalar register)
                     }
                 }
                 nee_pw.x = pw.x; nee_pw.y = pw.y; nee_pw.z = pw.z;
@@ -2026,11 +2126,11 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)
         // ---- block-aggregated queue appends (every thread of the block reaches this): one atomic per queue per block
         PT_SHADE_ARGS
         uint32_t* const ctrs[4] = {&io.ctr->n_shadow, &io.ctr->n_lchain, &io.ctr_next->n_closest, &io.ctr_next->n_shade[Q_TERMINAL]};
-        const bool preds[4] = {want_shadow, want_lchain, want_next, want_dead};
+        const bool preds[4] = {want_shadow && !INLINE, want_lchain, want_next, want_dead};
         const uint32_t caps[4] = {io.cap_slots, io.cap_slots, io.cap_slots, io.cap_slots_term};
         uint32_t pos[4];
         block_append4(sh_append, ctrs, preds, caps, &io.ctr->overflow, pos);
-        if (want_shadow) { nt_store(io.rq_shadow.a + pos[0], sh_a); nt_store(io.rq_shadow.b + pos[0], sh_b); }
+        if (want_shadow && !INLINE) { nt_store(io.rq_shadow.a + pos[0], sh_a); nt_store(io.rq_shadow.b + pos[0], sh_b); }
         if (want_lchain) { io.rq_lchain.a[pos[1]] = lc_a; io.rq_lchain.b[pos[1]] = lc_b; io.lchain_nb[pos[1]] = nee_b; nee_e.w = asf(pos[1]); }
         if (want_next) { nt_store(io.rq_out.a + pos[2], nx_a); nt_store(io.rq_out.b + pos[2], nx_b); }
         if (want_dead) io.q_term_next[pos[3]] = make_uint2(pid | ENTRY_DEAD, pid);
@@ -2063,8 +2163,50 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, shade_waves(QCLASS, VOLUMES)
             PT_QUAD_STORE(0, 0x00) PT_QUAD_STORE(1, 0x55) PT_QUAD_STORE(2, 0xAA) PT_QUAD_STORE(3, 0xFF)
 #undef PT_QUAD_STORE
         }
+        if (INLINE)
+        {
+            // the explicit-light shadow ray is answered here, after the record is on its way: what k_any<SHADOW> does to the record (put_result_at), same arithmetic
+            // (the stack's base is recomputed here, behind an opaque move, rather than kept in a register across the iteration)
+            // ... and so is the description of the staged scene (re-read from the kernel-argument segment like every other section's)
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const ShadeKArgs& ka2 = shade_args();
+            const uint32_t blob_words = ka2.sv.blob_bytes >> 4;
+            Blob bl;
+            bl.nodes = smem_dyn;
+            bl.tris = smem_dyn + 2u * ka2.sv.n_nodes;
+            bl.inst = smem_dyn + 2u * ka2.sv.n_nodes + 3u * ka2.sv.n_tris;
+            bl.leaves = reinterpret_cast<const uint2*>(smem_dyn + 2u * ka2.sv.n_nodes + 3u * ka2.sv.n_tris + INST_WORDS * ka2.sv.n_instances);
+            const Stack8<false> stk{reinterpret_cast<char*>(smem_dyn), blob_words * 16u + tid * 8u, blockDim.x * 8u};
+            traced += (uint32_t)__popcll(__ballot(want_shadow));
+            const bool blocked = inline_any(bl, stk, ka2.world_root, sh_a, sh_b, want_shadow);
+            if (want_shadow)
+            {
+                DPathRec* rec = shade_args().io.st.rec + pid;
+                if (ends_with_shadow)
+                {
+                    const f3 e = blocked ? f3{0.0f, 0.0f, 0.0f} : xyz(rec->nee_e);
+                    const f3 a2 = xyz(rec->acc) + xyz(rec->nee_pw) * (e + f3{0.0f, 0.0f, 0.0f});
+                    shade_args().io.st.radiance[pid] = f4{a2.x, a2.y, a2.z, 0.0f};
+                }
+                else if (blocked)
+                {
+                    float* e = reinterpret_cast<float*>(&rec->nee_e);
+                    e[0] = 0.0f; e[1] = 0.0f; e[2] = 0.0f;
+                }
+            }
+            a_next = (idx + stride) < n ? nt_load(shade_args().io.q_in.a + idx + stride) : hole_a;
+        }
     }
-    add_tally(io.lchain_heads, culled, HEAD_TALLY2);
+    if (!INLINE) add_tally(io.lchain_heads, culled, HEAD_TALLY2);
+    else if (lane_id() == 0u)
+    {
+        // (both counts are wave-uniform here)
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint32_t line = ((wave * 7u) & (kQueueHeads - 1u)) * kHeadStrideWords;
+        if (culled != 0u) atomicAdd(io.lchain_heads + line + HEAD_TALLY2, culled);
+        if (traced != 0u) atomicAdd(io.shadow_heads + line + HEAD_TALLY0, traced);
+    }
 }
 
 #undef PT_SHADE_ARGS
@@ -2433,8 +2575,16 @@ void launch_trace_lchain(hipStream_t s, const TraceLaunch& tl, const WavefrontBu
     out.occl = wb.st.occl;
     launch_closest_impl<CLOSEST_LIGHTS>(s, tl, tl.scene.lights_root, wb.rq_lchain[b & 1u], &row->n_lchain, wb.cap_slots, row_heads(wb, b, HEADS_LCHAIN), out);
 }
+// The Lambertian shading pass walks its own shadow rays when the scene's BVH and a workgroup's stacks take no more LDS than five workgroups per CU can share
+// (the pass keeps its five waves per SIMD), nothing spills from the stacks, the scene has no media (those kernels are short of registers as it is) and the
+// traversal workgroups have the shading pass's shape (the stack layout is per thread of a workgroup).
+bool shade_traces_shadow(const TraceLaunch& tl)
+{
+    return PT_INLINE_SHADOW != 0 && tl.lds_scene && tl.scene.stack_entries <= tl.scene.stack_lds && !tl.scene.has_volumes && tl.block_threads == PT_SHADE_THREADS &&
+           trace_lds_bytes(tl) + 1024 <= 32 * 1024;
+}
 void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const RenderParams& rp, const WavefrontBuffers& wb, uint32_t b,
-                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env)
+                  uint32_t grid_blocks, const CameraView& cam, const EnvView& env, const TraceLaunch* tl)
 {
     ShadeIO io{};
     io.env = env;
@@ -2461,14 +2611,18 @@ void launch_shade(hipStream_t s, uint32_t qclass, const SceneView& sv, const Ren
     io.cap_slots_shade = wb.cap_slots_shade;
     io.ctr = wb.counters + b;
     io.lchain_heads = row_heads(wb, b, HEADS_LCHAIN);
+    io.shadow_heads = row_heads(wb, b, HEADS_SHADOW);
     io.ctr_next = wb.counters + b + 1u;
     const uint32_t surface_blocks = (grid_blocks * 256u + PT_SHADE_THREADS - 1u) / PT_SHADE_THREADS; // grid_blocks is in units of 256 threads
-    const ShadeKArgs ka{sv, rp, io, b};
+    const bool inl = tl && shade_traces_shadow(*tl);
+    const ShadeKArgs ka{sv, rp, io, b, inl ? (const uint4*)tl->blob : nullptr, inl ? tl->scene.world_root : 0u};
+    const size_t lds = inl ? trace_lds_bytes(*tl) : 0;
     switch (qclass)
     {
     case Q_TERMINAL: hipLaunchKernelGGL(k_shade_terminal, dim3(grid_blocks), dim3(256), 0, s, sv, rp, io, b); break;
     case Q_LAMBERT:
-        if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
+        if (inl) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), lds, s, ka);
+        else if (sv.has_volumes) hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, true>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         else hipLaunchKernelGGL((k_shade_surface<Q_LAMBERT, false>), dim3(surface_blocks), dim3(PT_SHADE_THREADS), 0, s, ka);
         break;
     case Q_SPECULAR:

@@ -449,13 +449,16 @@ def test_full_queue_is_reported_not_overrun(api, oracle_mod):
     assert_bit_equal(tight.render_samples(0, 4), want, "same context with the default slack")
 
 
-def test_ray_queues_are_dense_and_shade_queues_nearly(api):
+@pytest.mark.parametrize("flags", [0, 2])   # 2 = PT_FLAG_NO_LDS_SCENE: the same scene with its BVH in global memory
+def test_ray_queues_are_dense_and_shade_queues_nearly(api, flags):
     """A shading workgroup reserves exactly what it appends: a bounce's ray-queue extents (slots) equal the rays traced from
     them (the claim-cursor tallies), nothing is a hole.  The shade queues are written in regions by the traversal waves over up to 64
     striped tails: their extents may exceed the hits by the waves' last regions and the stripes' gaps, a few per cent on a queue this
-    size (holes were measured to cost more than reservations: DESIGN.md section 4)."""
+    size (holes were measured to cost more than reservations: DESIGN.md section 4).
+    Shadow rays: with the BVH in LDS the Lambertian shading pass answers them itself (nothing is queued, the tally of traced rays is
+    the pass's own); with the BVH in global memory they are queued for k_any and the extent equals the tally.  Both runs cast the same rays."""
     from path_tracer_amd import scenes
-    r = api.Renderer(scenes.cornell_box(960, 540), 960, 540, max_bounces=6)
+    r = api.Renderer(scenes.cornell_box(960, 540), 960, 540, max_bounces=6, flags=flags)
     r.render_device(0, 8)
     r.synchronize()
     rows = r.last_batch_counters().astype(np.int64)
@@ -463,10 +466,19 @@ def test_ray_queues_are_dense_and_shade_queues_nearly(api):
     for b in range(1, 7):
         n_closest, n_shadow, n_lchain = rows[b][0], rows[b - 1][2], rows[b - 1][4]
         assert n_closest == rows[b][13], (b, n_closest, rows[b][13])              # continuation rays of bounce b
-        assert n_shadow == rows[b - 1][14], (b, n_shadow, rows[b - 1][14])        # shadow rays cast by bounce b-1's shading
+        assert rows[b - 1][14] > 0
+        assert n_shadow == (rows[b - 1][14] if flags else 0), (b, n_shadow, rows[b - 1][14])   # shadow rays cast by bounce b-1's shading
         assert n_lchain == rows[b - 1][6], (b, n_lchain, rows[b - 1][6])          # BSDF-sampled NEE rays that passed the lights' root box
         lambert_slots = rows[b][9]
         assert n_closest * 0.5 < lambert_slots <= n_closest * 1.06 + 4096 * 64, (b, lambert_slots, n_closest)
+    if flags:
+        return
+    # the two routes cast the same shadow rays
+    r2 = api.Renderer(scenes.cornell_box(960, 540), 960, 540, max_bounces=6, flags=2)
+    r2.render_device(0, 8)
+    r2.synchronize()
+    rows2 = r2.last_batch_counters().astype(np.int64)
+    assert [int(x) for x in rows[:7, 14]] == [int(x) for x in rows2[:7, 14]]
 
 
 def test_scene_edit_adds_a_material_class(api, oracle_mod):

@@ -22,7 +22,7 @@
 using namespace pt;
 
 #ifndef PT_SHADE_BLOCKS_PER_CU
-#define PT_SHADE_BLOCKS_PER_CU 12  // persistent shading workgroups per CU (same-box sweep over 4, 6, 8, 12, 16)
+#define PT_SHADE_BLOCKS_PER_CU 16  // persistent shading workgroups per CU (same-box sweeps: rounds 1-3 over 4, 6, 8, 12, 16 -> 12; round 4, with the shadow walk inside the Lambertian pass, 5 / 10 / 12 / 15 / 16 / 20: one-pipeline Cornell frame 60.9 / 59.6 / 60.4 / 59.3 / 59.9 / 58.9 ms, 1/4 share 16.6 (12) / 16.1 / 15.9 / 16.0, global-BVH scenes +-0)
 #endif
 #ifndef PT_JOIN_LATE
 #define PT_JOIN_LATE 0 // same-box A/B: joining the side stream only before the shading pass costs +2 ms per frame (the two traversal kernels fight for wave slots), 0.1 ms less for a 1/8 share

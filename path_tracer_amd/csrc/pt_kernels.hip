@@ -1878,7 +1878,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, INLINE ? PT_SHADE_WAVES_INLI
         const f4 rb = a_next;
         if (!INLINE) a_next = (idx + stride) < n ? nt_load(io.q_in.a + idx + stride) : hole_a; // (INLINE: requested after the shadow walk, which wants the registers)
         bool valid = idx < n && stripe_valid(sh_tail, stripes, idx) && asu(rb.w) != HOLE;
-        bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false;
+        bool want_shadow = false, want_lchain = false, want_next = false, want_dead = false, ends_with_shadow = false, cull_now = false;
         f4 sh_a{}, sh_b{}, lc_a{}, lc_b{}, nx_a{}, nx_b{};
         uint32_t pid = 0, flags = 0;
         f3 acc{}, pw{};
@@ -2077,7 +2077,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, INLINE ? PT_SHADE_WAVES_INLI
                             flags |= FLAG_BSDF_CAST;
                         }
                         else if (!INLINE) culled += 1u;
-                        if (INLINE) culled += (uint32_t)__popcll(__ballot(!may_hit)); // (wave-uniform count in a scalar register)
+                        else cull_now = true;
                     }
                 }
                 nee_pw.x = pw.x; nee_pw.y = pw.y; nee_pw.z = pw.z;
@@ -2178,7 +2178,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, INLINE ? PT_SHADE_WAVES_INLI
             bl.inst = smem_dyn + 2u * ka2.sv.n_nodes + 3u * ka2.sv.n_tris;
             bl.leaves = reinterpret_cast<const uint2*>(smem_dyn + 2u * ka2.sv.n_nodes + 3u * ka2.sv.n_tris + INST_WORDS * ka2.sv.n_instances);
             const Stack8<false> stk{reinterpret_cast<char*>(smem_dyn), blob_words * 16u + tid * 8u, blockDim.x * 8u};
-            traced += (uint32_t)__popcll(__ballot(want_shadow));
+            traced += (uint32_t)__popcll(__ballot(want_shadow)); // (both counted here, where the whole wave is: wave-uniform values in scalar registers)
+            culled += (uint32_t)__popcll(__ballot(cull_now));
             const bool blocked = inline_any(bl, stk, ka2.world_root, sh_a, sh_b, want_shadow);
             if (want_shadow)
             {

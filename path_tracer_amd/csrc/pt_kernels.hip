@@ -8,6 +8,7 @@
 //   k_any           tlas.rs:111-144 + blas.rs:257-294   (shadow rays; finishes paths that died owing one explicit-light estimate)
 //   k_shade_surface<class>, k_shade_terminal   integrator.rs:163-270 split per material class; the NEE of the previous bounce is
 //                   resolved first; BSDF-sampled NEE rays that miss the lights' root box are answered on the spot
+//                   (LDS-resident scenes: the Lambertian pass also walks its own explicit-light shadow rays, inline_any: no shadow queue, no k_any launch)
 //   k_accumulate    integrator.rs:272-280 + accumulate.wgsl:20-23 in sample order
 //
 // Arithmetic: pt_math.h / pt_materials.h.  Built with -ffp-contract=off; v_min/v_max are used in the slab test only
@@ -132,7 +133,9 @@ constexpr int shade_waves(uint32_t qclass, bool volumes)
 {
     return volumes ? PT_SHADE_WAVES_VOLUMES : (qclass == Q_GGX ? PT_SHADE_WAVES_GGX : (qclass == Q_DIELECTRIC ? PT_SHADE_WAVES_DIEL : PT_SHADE_WAVES));
 }
-// LDS-resident scenes: the shading pass traces its explicit-light shadow ray itself (inline_any) instead of queueing it for k_any<SHADOW>
+// LDS-resident scenes: the Lambertian shading pass traces its explicit-light shadow ray itself (inline_any) instead of queueing it for k_any<SHADOW>: same box,
+// Cornell frame 58.45 -> 57.5 ms, one pipeline 62.1 -> 59.8, 1/4 and 1/8 share 16.4 / 9.4 -> 15.6 / 8.95, mixed materials 64 spp 21.1 -> 20.0.  At four waves per SIMD
+// (PT_SHADE_WAVES_INLINE, 128 VGPRs) it wins on one pipeline only (61.7) and loses the two-pipeline overlap (61.5); five waves need the walk AFTER the record store.
 #ifndef PT_INLINE_SHADOW
 #define PT_INLINE_SHADOW 1
 #endif

@@ -47,8 +47,9 @@ def main(src, tag):
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for _, r in ks.iterrows():
         lines.append(f"| {r['kernel']} | {r['Calls']} | {r['TotalDurationNs'] / 1e6:.2f} | {r['AverageNs'] / 1e3:.1f} | {r['Percentage']:.2f} |")
-    lines += ["", "`k_closest<.., 1, ..>` (the BSDF-sampled NEE rays, about 1 % of them since the shading pass culls the rest) is launched on a side stream "
-              "beside `k_any`: its duration overlaps `k_any`'s and mostly measures waiting for wave slots, so the column sums exceed the wall time."]
+    lines += ["", "`k_closest<.., 1, ..>` (the BSDF-sampled NEE rays, about 1 % of them since the shading pass culls the rest): where it is a launch of its own it runs on a side "
+              "stream beside `k_any` and its duration mostly measures waiting for wave slots, so the column sums can exceed the wall time.  `k_shade_surface<1u, false, true>` is the "
+              "Lambertian pass that walks its own shadow rays (LDS-resident scenes, round 4): no `k_any` row then, unless GGX surfaces queue theirs."]
     kt_ms = {r["kernel"]: r["TotalDurationNs"] / 1e6 for _, r in ks.iterrows()}
     kt_steps = 2.0
     traffic = {}
@@ -119,7 +120,9 @@ def main(src, tag):
                                       "GBps": (sb / spp_p * spp_kt) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None}
         if s_ms > 0:
             gbps = traffic["k_shade_surface"]["GBps"]
-            lines += ["", f"Shading pass (k_shade_surface, all launches): {sb / 1e9:.2f} GB per {spp_p}-spp step by the counters = {sb / spp_p / 1e6:.1f} MB per spp; "
+            inl = any(k.endswith(", true>") for k in sk)
+            lines += ["", f"Shading pass (k_shade_surface, all launches{'; the Lambertian launches include their shadow walk, which moves no bytes' if inl else ''}): "
+                      f"{sb / 1e9:.2f} GB per {spp_p}-spp step by the counters = {sb / spp_p / 1e6:.1f} MB per spp; "
                       f"{s_ms:.2f} ms per {spp_kt}-spp step in the kernel trace -> **{gbps:.0f} GB/s = {gbps / 8000:.2f} of the 8 TB/s peak**."]
     except Exception as e:  # noqa: BLE001
         lines += ["", f"(bytes per ray not derived: {e})"]

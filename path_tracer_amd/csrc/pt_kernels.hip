@@ -72,6 +72,9 @@ namespace {
 #ifndef PT_BRANCH_LEVELS_ANY
 #define PT_BRANCH_LEVELS_ANY 4
 #endif
+#ifndef PT_BRANCH_LEVELS_INLINE
+#define PT_BRANCH_LEVELS_INLINE 6 // ... of the shadow walk inside the Lambertian shading pass (inline_any; no refill there, so fewer, longer steps: same-box 1 / 2 / 3 / 4 / 6 / 8: Cornell frame 59.05 / 57.9 / 57.8 / 57.4 / 56.95 / 56.9 ms, one pipeline 60.8 / 59.9 / 59.9 / 59.3 / 59.0 / 59.3)
+#endif
 // frames with fewer local pixels than this use four lanes per pixel in k_accumulate (k_accumulate<FEW_PIXELS>)
 #ifndef PT_ACC_QUAD_BELOW
 #define PT_ACC_QUAD_BELOW (1u << 30) // (whole 1080p frame: 0.675 -> 0.55 ms; beyond 2^30 pixels the thread index would overflow)
@@ -1778,7 +1781,7 @@ __device__ __forceinline__ bool inline_any(const Blob& bl, const Stack8<false>& 
         }
         uint32_t kind = link >> NODE_KIND_SHIFT, payload = link & NODE_PAYLOAD_MASK;
 #pragma unroll 1
-        for (int lvl = 0; lvl < PT_BRANCH_LEVELS_ANY && kind == NODE_BRANCH; ++lvl)
+        for (int lvl = 0; lvl < PT_BRANCH_LEVELS_INLINE && kind == NODE_BRANCH; ++lvl)
         {
             const uint4* cp = bl.nodes + 2u * payload;
             const uint4 l0 = cp[0], l1 = cp[1], r0 = cp[2], r1 = cp[3];
@@ -1792,7 +1795,7 @@ __device__ __forceinline__ bool inline_any(const Blob& bl, const Stack8<false>& 
             {
                 const uint2 next = hr ? make_uint2(r0.w, asu(tr)) : make_uint2(l0.w, asu(tl));
                 const uint32_t nk = next.x >> NODE_KIND_SHIFT;
-                if ((nk & 1u) != 0u || (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS_ANY))
+                if ((nk & 1u) != 0u || (nk == NODE_BRANCH && lvl + 1 < PT_BRANCH_LEVELS_INLINE))
                 {
                     kind = nk;
                     payload = next.x & NODE_PAYLOAD_MASK;

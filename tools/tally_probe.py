@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Shadow-ray tallies of the two routes (GPU box): the Lambertian shading pass walking its own shadow rays (BVH in LDS) against the
+queue + k_any route (PT_FLAG_NO_LDS_SCENE), per bounce row and in pt_stats, at several sample counts on one and two pipelines."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np

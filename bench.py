@@ -293,7 +293,7 @@ def main():
         ksh = (prof or {}).get("k_shade_surface")
         if ksh and kernel_ms and kernel_ms["shade"] > 0 and ksh.get("hbm_bytes_per_spp"):
             gb = ksh["hbm_bytes_per_spp"] * spp / 1e9
-            out["roofline_shade"] = {"kernel": "k_shade_surface (all launches of a step)", "counter_GB_per_step": gb, "ms_per_step": kernel_ms["shade"],
+            out["roofline_shade"] = {"kernel": "k_shade_surface (all launches of a step" + ("; the Lambertian launches of this LDS-resident scene include their inline shadow walk, which moves no bytes: the pass is VALU-bound, this is its byte rate, not its limit)" if lds_scene else ")"), "counter_GB_per_step": gb, "ms_per_step": kernel_ms["shade"],
                                      "counter_GBps": gb / (kernel_ms["shade"] * 1e-3), "frac_of_8000": gb / (kernel_ms["shade"] * 1e-3) / HBM_PEAK_GBS,
                                      "source": f"profiles/{pname}: FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the shading launches per spp, x this run's spp, over this run's kernel_ms.shade"}
         print(json.dumps(out), flush=True)
